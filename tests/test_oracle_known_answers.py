@@ -1,0 +1,47 @@
+"""The oracle's BVH build, traversal state machine, light loop and frame loop against the known answers
+recorded from a run of the reference renderer (default camera: fov 50, distance 3, rotation (20,20,0);
+prebuilt scenes).  Those reference units cannot be linked in this image, so these totals - which depend
+on the build order, the fixed child order, the origin-inside-box rule and the uncut shadow-ray walks -
+are what pins them."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("name,tris,nodes,levels", [
+    ("single_triangle", 1, 1, 1), ("cube", 12, 23, 5), ("cube_textured", 12, 23, 5), ("cornell", 32, 63, 6),
+    ("monkey", 967, 1933, 11), ("teapot", 15704, 31407, 15)])
+def test_bvh_shape(orc, scenes, name, tris, nodes, levels):
+    b = orc.Bvh(scenes(name), orc.F_ACCEL)
+    assert (b.num_leaves, b.num_nodes, b.num_levels) == (tris, nodes, levels)
+    meta, _ = b.dump()
+    assert meta[-1, 1] == 0 and (nodes == 1 or meta[-1, 0] == 0)  # root is the last node, level 0
+
+
+def test_cornell_primary_hit(orc, scenes):
+    b = orc.Bvh(scenes("cornell"), orc.F_ACCEL)
+    r = b.render(orc.make_camera(64, 64), orc.F_ACCEL)
+    x, y = 40, 16  # loop coordinates, y up; Screen stores row H-1-y
+    assert r["mesh"][63 - y, x] == 0 and r["tri"][63 - y, x] == 1
+    assert abs(float(r["t"][63 - y, x]) - 2.64017606) < 5e-8
+
+
+def test_cornell_frame_totals(orc, scenes):
+    b = orc.Bvh(scenes("cornell"), orc.F_ACCEL)
+    f = orc.F_ACCEL | orc.F_SHADING | orc.F_RECURSIVE | orc.F_HARD_SHADOW
+    c = b.render(orc.make_camera(1024, 1024), f)["counters"]
+    assert c["path_rays"] + c["shadow_rays"] == 1328237
+    assert round(c["node_visits"] / 1e5) == 201  # 20.1 M
+
+
+def test_teapot_frame_totals(orc, scenes):
+    b = orc.Bvh(scenes("teapot"), orc.F_ACCEL)
+    f = orc.F_ACCEL | orc.F_SHADING | orc.F_HARD_SHADOW
+    cam = orc.make_camera(480, 270)
+    full = b.render(cam, f)
+    c = full["counters"]
+    assert (c["path_rays"], c["shadow_rays"]) == (129600, 8874)
+    assert round(c["node_visits"] / 1e5) == 2623  # 262.3 M: every unoccluded shadow ray walks the whole tree
+    # culling boxes whose slab test fails must not change this frame, only the work
+    cull = b.render(cam, f | orc.F_MISS_CULL)
+    assert np.array_equal(full["tri"], cull["tri"]) and np.array_equal(full["rgb"], cull["rgb"])
+    assert cull["counters"]["node_visits"] < c["node_visits"] // 100
