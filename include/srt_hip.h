@@ -1,0 +1,227 @@
+/*
+ * srt_hip.h -- C ABI of libsrt_hip.so: the MI355X (gfx950) back end for the ray tracer's hot path.
+ *
+ * Plain C, plain pointers and sizes, no exceptions across the boundary.  Every function returns SRT_OK (0)
+ * or a negative status; srt_last_error() gives the message of the calling thread's last failure.
+ *
+ * The library replaces the body of the reference's frame function and of its per-ray BVH query:
+ *   renderRayTracing(scene, camera, bvh, screen, features, ...)      reference src/render.h:17, src/render.cpp:180-234
+ *   BvhInterface::intersect(Ray&, HitInfo&, const Features&) const    reference src/bvh_interface.h:38,
+ *                                                                     src/bounding_volume_hierarchy.cpp:316-393
+ * The host side (Scene / BvhInterface / Screen / Trackball mirrors in simple-ray-tracer_amd/host) builds the
+ * BVH exactly as the reference does, flattens it into the arrays below and calls these entry points.
+ *
+ * Threading: a handle is used by one host thread at a time; distinct handles are independent.
+ */
+#ifndef SRT_HIP_H
+#define SRT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRT_OK 0
+#define SRT_ERR_INVALID (-1) /* bad argument or scene that breaks a documented limit */
+#define SRT_ERR_HIP (-2)     /* a HIP runtime call failed; message carries hipGetErrorString */
+#define SRT_ERR_NO_DEVICE (-3)
+
+/* Feature bits: struct Features / ExtraFeatures, reference src/common.h:55-80. */
+#define SRT_F_SHADING (1u << 0)
+#define SRT_F_RECURSIVE (1u << 1)
+#define SRT_F_HARD_SHADOW (1u << 2)
+#define SRT_F_SOFT_SHADOW (1u << 3)
+#define SRT_F_NORMAL_INTERP (1u << 4)
+#define SRT_F_TEXTURE (1u << 5)
+#define SRT_F_ACCEL (1u << 6)
+#define SRT_F_MULTISAMPLE (1u << 7)
+/* Traversal policy.  0: the reference's exact visiting rule (a shadow ray walks the whole tree until its
+ * first hit).  1: additionally skip every box whose slab test fails; same result up to rounding of
+ * hit points, orders of magnitude less work.  The host mirror sets it by default. */
+#define SRT_F_MISS_CULL (1u << 16)
+
+#define SRT_LEAF_FLAG 0x80000000u
+#define SRT_MAX_TRIS (1u << 24)  /* triangle index field of a packed child reference */
+#define SRT_MAX_LEAF_TRIS 127u   /* count field of a packed child reference */
+#define SRT_MAX_LEVELS 30        /* per-lane traversal stack capacity is levels + 1 */
+
+/* One inner node, 64 bytes, 64-byte aligned in device memory.  Holds BOTH children's boxes (the
+ * reference tests a child's box while visiting the parent, src/bounding_volume_hierarchy.cpp:370-376)
+ * and both child references.  A child reference is
+ *     inner child: index into the node array
+ *     leaf child : SRT_LEAF_FLAG | count << 24 | first triangle (position in the leaf-ordered streams)
+ * Node 0 is the root when the root is an inner node; nodes are stored breadth first. */
+typedef struct srt_node {
+    float lbox[6]; /* left child: lower xyz, upper xyz */
+    float rbox[6]; /* right child */
+    uint32_t left;
+    uint32_t right;
+    uint32_t left_level; /* reference "level" of the children (root = 0); informational */
+    uint32_t pad;
+} srt_node;
+
+/* Traversal stream, one 96-byte record per triangle in leaf order.  Everything ray independent in the
+ * reference's ray/triangle test is precomputed WITH THE REFERENCE'S OPERATIONS (src/intersect.cpp:13-77):
+ *   n, D    = trianglePlane(v0, v1, v2)            (n = 0, D = 0 for a zero-area triangle)
+ *   c0      = cross(v2 - v1, v0 - v1)              second operand of sameSide(p, v0, v1, v2)
+ *   c1      = cross(v2 - v0, v1 - v0)              second operand of sameSide(p, v1, v0, v2)
+ *   c2      = cross(v1 - v0, v2 - v0)              second operand of sameSide(p, v2, v0, v1) */
+typedef struct srt_tri {
+    float n[3];
+    float D;
+    float v0[3];
+    uint32_t mesh; /* scene mesh index */
+    float v1[3];
+    uint32_t tri;  /* triangle index inside the mesh */
+    float v2[3];
+    float c0[3];
+    float c1[3];
+    float c2[3];
+} srt_tri; /* 24 words: read as six 16-byte loads */
+
+/* Shading stream, one 64-byte record per triangle in leaf order: vertex normals, texture coordinates. */
+typedef struct srt_tri_attr {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    uint32_t mesh;
+} srt_tri_attr;
+
+/* struct Material, reference framework/include/framework/mesh.h:22-34 (one per mesh). */
+typedef struct srt_material {
+    float kd[3];
+    float ks[3];
+    float shininess;
+    float transparency;
+    int32_t texture; /* index into textures or -1 */
+    int32_t pad[3];
+} srt_material;
+
+typedef struct srt_texture {
+    uint32_t width, height;
+    uint64_t offset; /* first pixel in texels, in pixels */
+} srt_texture;
+
+/* Lights, reference src/common.h:38-53.  type: 0 point {position, color}; 1 segment {endpoint0, endpoint1,
+ * color0, color1}; 2 parallelogram {v0, edge01, edge02, color0..3}; floats in declaration order. */
+typedef struct srt_light {
+    uint32_t type;
+    float f[21];
+    uint32_t pad[2];
+} srt_light;
+
+typedef struct srt_scene_desc {
+    const srt_node* nodes;
+    uint32_t n_nodes;
+    float root_box[6];
+    uint32_t root_ref;   /* child-reference encoding; a scene with <= 1 triangle has a leaf root */
+    uint32_t num_levels; /* BoundingVolumeHierarchy::numLevels() */
+    const srt_tri* tris;
+    const srt_tri_attr* attrs;
+    uint32_t n_tris;
+    const uint32_t* scene_order; /* leaf-order position of the k-th triangle in (mesh, triangle) order;
+                                    drives the accel-structure-off path (:319-332) */
+    const srt_material* materials;
+    uint32_t n_materials;
+    const srt_texture* textures;
+    uint32_t n_textures;
+    const float* texels; /* RGB float, row-major, top row first (framework/src/image.cpp:22-32) */
+    uint64_t n_texels;
+    const srt_light* lights;
+    uint32_t n_lights;
+} srt_scene_desc;
+
+/* Camera constants: Trackball::position / generateRay, reference framework/src/trackball.cpp:71-74,101-110
+ * (the quaternion is ray independent and is built once on the host). */
+typedef struct srt_camera {
+    float origin[3];
+    float quat[4]; /* w, x, y, z */
+    float half_w, half_h;
+    int32_t width, height;
+} srt_camera;
+
+/* Result of one BVH query; mirrors what the reference leaves in Ray::t and HitInfo. */
+typedef struct srt_hit {
+    int32_t hit;
+    float t;
+    int32_t mesh, tri; /* -1 on a miss */
+    float normal[3];
+    float bary[3];
+    float uv[2];
+    float kd[3];
+} srt_hit;
+
+typedef struct srt_counters {
+    uint64_t path_rays;    /* camera + reflection queries */
+    uint64_t shadow_rays;  /* shadow queries */
+    uint64_t shaded_hits;
+    uint64_t inner_visits; /* counted only with SRT_RENDER_STATS / in srt_intersect_batch */
+    uint64_t tri_tests;
+    uint64_t box_tests;
+} srt_counters;
+
+typedef struct srt_render_params {
+    srt_camera camera;
+    uint32_t features;
+    int32_t samples_x, samples_y; /* used when SRT_F_MULTISAMPLE is set; the reference has x == y == numRays */
+    int32_t max_depth;            /* reflect while depth < max_depth; the reference hard-codes 5 */
+    uint32_t seed;                /* soft-shadow sampler */
+    int32_t rect[4];              /* x0, y0, x1, y1: pixels [x0,x1) x [y0,y1), y counted upwards as in render.cpp:187-188 */
+    uint32_t flags;               /* SRT_RENDER_* */
+} srt_render_params;
+
+#define SRT_RENDER_STATS (1u << 0)  /* also count node visits / triangle tests (slower kernels) */
+#define SRT_RENDER_TIMING (1u << 1) /* bracket every launch with HIP events for srt_device_last_kernel_ms */
+
+/* Where a rendered pixel (x, y) goes: element ((out_height - 1 - (y - y0)) * out_width + (x - x0)) of each
+ * output array, i.e. Screen::setPixel's layout (reference src/screen.cpp:85-91) for a buffer that covers
+ * pixels [x0, x0 + out_width) x [y0, y0 + out_height).  A whole-frame Screen is x0 = y0 = 0, W x H. */
+typedef struct srt_output {
+    float* rgb;          /* 3 floats per pixel; required */
+    int32_t* prim_mesh;  /* optional: primary hit of sample 0, mesh index or -1 */
+    int32_t* prim_tri;   /* optional: triangle index inside the mesh or -1 */
+    float* prim_t;       /* optional: its Ray::t (FLT_MAX on a miss) */
+    int32_t out_width, out_height, x0, y0;
+    int32_t on_device;   /* 0: host pointers (copied back, call returns when done); 1: device pointers
+                            (work is only enqueued on the stream) */
+} srt_output;
+
+typedef struct srt_device srt_device;
+typedef struct srt_scene srt_scene;
+
+const char* srt_last_error(void);
+int srt_device_count(int* count);
+int srt_device_create(int gpu_id, srt_device** out);
+void srt_device_destroy(srt_device* dev);
+/* Streams are passed as hipStream_t cast to void*; NULL is the default stream. */
+int srt_device_synchronize(srt_device* dev, void* stream);
+/* Totals since the last reset; synchronizes the stream first. */
+int srt_device_read_counters(srt_device* dev, void* stream, srt_counters* out, int reset);
+/* Milliseconds spent in each kernel family by the most recent srt_render call (HIP events recorded on
+ * the call's stream): [0] primary trace, [1] secondary trace, [2] shade, [3] resolve.  Synchronizes. */
+int srt_device_last_kernel_ms(srt_device* dev, float ms[4]);
+
+/* Copies every array of the description to device memory; the host arrays stay with the caller. */
+int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);
+void srt_scene_destroy(srt_scene* scene);
+
+/* renderRayTracing for one rectangle of the frame. */
+int srt_render(srt_device* dev, srt_scene* scene, const srt_render_params* params, const srt_output* out,
+               void* stream);
+
+/* BvhInterface::intersect for n rays (host arrays; 7 floats per ray: origin, direction, t).  The ray's t is
+ * updated in place; hits carries what the reference leaves in HitInfo.  Always counts node visits. */
+int srt_intersect_batch(srt_device* dev, srt_scene* scene, float* rays7, int64_t n, uint32_t features,
+                        srt_hit* hits, srt_counters* counters);
+
+/* getFinalColor (reference src/render.h:20, src/render.cpp:83-150) for n caller-supplied rays (host arrays;
+ * rgb: 3 floats per ray).  Ray i uses sampler key i for soft shadows. */
+int srt_final_color_batch(srt_device* dev, srt_scene* scene, const float* rays7, int64_t n, uint32_t features,
+                          int32_t max_depth, uint32_t seed, float* rgb);
+
+/* Trackball::generateRay for n normalized pixel positions (host arrays; ndc: 2 floats, rays: 7 floats). */
+int srt_generate_rays(srt_device* dev, const srt_camera* camera, const float* ndc2, int64_t n, float* rays7);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -7,6 +7,7 @@ checkout exists; the fixtures it writes are plain data (inputs and the reference
                                    (loadScenePrebuilt -> loadMesh -> tinyobj/stb; src/scene.cpp:5-94)
   tests/golden/leaf_math.npz       inputs and reference outputs of the leaf functions
   tests/golden/camera.npz          glm camera arithmetic as used by framework/src/trackball.cpp
+  tests/golden/obj_cases/*.npz     the reference loader's output for the OBJ files authored in that directory
 """
 import ctypes as C
 import os
@@ -206,10 +207,28 @@ def gen_camera():
     np.savez_compressed(os.path.join(GOLD, "camera.npz"), **g)
 
 
+def gen_obj_cases():
+    """The reference loader (loadMesh) on the OBJ files authored under tests/golden/obj_cases."""
+    R = orc.ref()
+    case_dir = os.path.join(GOLD, "obj_cases")
+    for fn in sorted(os.listdir(case_dir)):
+        if not fn.endswith(".obj"):
+            continue
+        for normalize in (0, 1):
+            h = R.ref_scene_load_file(os.path.join(case_dir, fn).encode(), normalize)
+            assert h, fn
+            d = orc.ref_scene_to_dict(h)
+            R.ref_scene_free(h)
+            out = os.path.join(case_dir, f"{fn[:-4]}.norm{normalize}.npz")
+            np.savez_compressed(out, **{k: d[k] for k in orc.SCENE_KEYS})
+            print(f"{fn} normalize={normalize}: meshes={len(d['materials'])} verts={len(d['verts'])} tris={len(d['tris'])}")
+
+
 if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
     scenes = gen_scenes()
     gen_leaf(scenes)
     gen_camera()
+    gen_obj_cases()
     print("golden fixtures written to", GOLD)

@@ -1,0 +1,395 @@
+"""simple-ray-tracer_amd: MI355X-native back end for the Simple-Ray-Tracer BVH / intersection / shading path.
+
+This module is a thin ctypes binding of host/libsrt_host.so (the C++ mirror of the reference's
+Scene / BvhInterface / Screen / renderRayTracing interface), which in turn drives csrc/libsrt_hip.so (the
+hand-written gfx950 kernels behind the C ABI of include/srt_hip.h).  There is no CPU rendering path: if the
+libraries are missing, or no GPU is visible, calls raise.
+
+Import with importlib (the directory name carries a hyphen):
+    srt = importlib.import_module("simple-ray-tracer_amd")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(HERE, "csrc", "libsrt_hip.so")
+HOST_LIB = os.path.join(HERE, "host", "libsrt_host.so")
+
+# feature bits (include/srt_hip.h)
+F_SHADING = 1 << 0
+F_RECURSIVE = 1 << 1
+F_HARD_SHADOW = 1 << 2
+F_SOFT_SHADOW = 1 << 3
+F_NORMAL_INTERP = 1 << 4
+F_TEXTURE = 1 << 5
+F_ACCEL = 1 << 6
+F_MULTISAMPLE = 1 << 7
+F_SAH = 1 << 8           # host-side build option (extra.enableBvhSahBinning)
+F_MISS_CULL = 1 << 16    # traversal policy; clear it for the reference's exact visiting rule
+
+RENDER_STATS = 1 << 0
+RENDER_TIMING = 1 << 1
+
+LIGHT_STRIDE = 22
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+
+class SrtError(RuntimeError):
+    pass
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("quat", C.c_float * 4), ("half_w", C.c_float), ("half_h", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("camera", Camera), ("features", C.c_uint32), ("samples_x", C.c_int32), ("samples_y", C.c_int32),
+                ("max_depth", C.c_int32), ("seed", C.c_uint32), ("rect", C.c_int32 * 4), ("flags", C.c_uint32)]
+
+
+class Output(C.Structure):
+    _fields_ = [("rgb", C.c_void_p), ("prim_mesh", C.c_void_p), ("prim_tri", C.c_void_p), ("prim_t", C.c_void_p),
+                ("out_width", C.c_int32), ("out_height", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32),
+                ("on_device", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("path_rays", "shadow_rays", "shaded_hits", "inner_visits", "tri_tests", "box_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("t", "<f4"), ("mesh", "<i4"), ("tri", "<i4"), ("normal", "<f4", 3),
+                      ("bary", "<f4", 3), ("uv", "<f4", 2), ("kd", "<f4", 3)])
+NODE_DTYPE = np.dtype([("lbox", "<f4", 6), ("rbox", "<f4", 6), ("left", "<u4"), ("right", "<u4"), ("left_level", "<u4"),
+                       ("pad", "<u4")])
+TRI_DTYPE = np.dtype([("n", "<f4", 3), ("D", "<f4"), ("v0", "<f4", 3), ("mesh", "<u4"), ("v1", "<f4", 3), ("tri", "<u4"),
+                      ("v2", "<f4", 3), ("c0", "<f4", 3), ("c1", "<f4", 3), ("c2", "<f4", 3)])
+ATTR_DTYPE = np.dtype([("n0", "<f4", 3), ("n1", "<f4", 3), ("n2", "<f4", 3), ("uv0", "<f4", 2), ("uv1", "<f4", 2),
+                       ("uv2", "<f4", 2), ("mesh", "<u4")])
+assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 96 and ATTR_DTYPE.itemsize == 64 and HIT_DTYPE.itemsize == 60
+
+# every symbol include/srt_hip.h declares
+HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "srt_device_destroy",
+                   "srt_device_synchronize", "srt_device_read_counters", "srt_device_last_kernel_ms",
+                   "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_intersect_batch",
+                   "srt_final_color_batch", "srt_generate_rays")
+
+
+def build():
+    """Compile both libraries in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+_host = None
+
+
+def host():
+    """libsrt_host.so; raises when the product libraries have not been built."""
+    global _host
+    if _host is not None:
+        return _host
+    for p in (HIP_LIB, HOST_LIB):
+        if not os.path.exists(p):
+            raise SrtError(f"{p} is missing: run `make -C {HERE}` (there is no CPU fallback)")
+    L = C.CDLL(HOST_LIB)
+    L.srth_last_error.restype = C.c_char_p
+    L.srth_scene_create.restype = C.c_void_p
+    L.srth_scene_destroy.argtypes = [C.c_void_p]
+    L.srth_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p]
+    L.srth_scene_add_mesh.argtypes = [C.c_void_p, _f32p, C.c_int, _u32p, C.c_int, _f32p, C.c_int]
+    L.srth_scene_add_light.argtypes = [C.c_void_p, _f32p]
+    L.srth_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    L.srth_scene_load_prebuilt.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    L.srth_scene_num_meshes.argtypes = [C.c_void_p]
+    L.srth_scene_num_lights.argtypes = [C.c_void_p]
+    L.srth_scene_mesh_sizes.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+    L.srth_scene_mesh_get.argtypes = [C.c_void_p, C.c_int, _f32p, _u32p, _f32p, _i32p]
+    L.srth_scene_mesh_texture.argtypes = [C.c_void_p, C.c_int, _f32p]
+    L.srth_scene_light_get.argtypes = [C.c_void_p, C.c_int, _f32p]
+    L.srth_hostbvh_create.restype = C.c_void_p
+    L.srth_hostbvh_create.argtypes = [C.c_void_p, C.c_uint32]
+    L.srth_hostbvh_destroy.argtypes = [C.c_void_p]
+    for n in ("srth_hostbvh_num_levels", "srth_hostbvh_num_leaves", "srth_hostbvh_num_nodes"):
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.srth_hostbvh_dump.argtypes = [C.c_void_p, _i32p, _f32p]
+    L.srth_hostbvh_tri_order.argtypes = [C.c_void_p, _i32p]
+    L.srth_hostbvh_flatten.argtypes = [C.c_void_p, C.c_int, _u32p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _f32p, _u32p]
+    L.srth_bvh_create.restype = C.c_void_p
+    L.srth_bvh_create.argtypes = [C.c_void_p, C.c_uint32]
+    L.srth_bvh_destroy.argtypes = [C.c_void_p]
+    L.srth_bvh_num_levels.argtypes = [C.c_void_p]
+    L.srth_bvh_num_leaves.argtypes = [C.c_void_p]
+    L.srth_bvh_intersect.argtypes = [C.c_void_p, _f32p, C.c_int64, C.c_uint32, C.c_void_p, C.POINTER(Counters)]
+    L.srth_final_color.argtypes = [C.c_void_p, _f32p, C.c_int64, C.c_uint32, C.c_int, C.c_uint32, _f32p]
+    L.srth_camera_make.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, C.POINTER(Camera)]
+    L.srth_generate_rays.argtypes = [C.POINTER(Camera), _f32p, C.c_int64, _f32p]
+    L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
+    L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
+    L.srth_last_kernel_ms.argtypes = [C.c_void_p, _f32p]
+    L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
+    L.srth_write_bmp.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int]
+    L.srth_set_device.argtypes = [C.c_int]
+    _host = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SrtError(host().srth_last_error().decode())
+
+
+def _p(a, t=_f32p):
+    return a.ctypes.data_as(t)
+
+
+def set_device(gpu):
+    """Select (and initialise) the GPU used by objects created afterwards on this thread."""
+    _check(host().srth_set_device(int(gpu)))
+
+
+class Scene:
+    """Mirror of the reference's Scene: a list of meshes (each with one material) and lights."""
+
+    def __init__(self):
+        self.h = host().srth_scene_create()
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host().srth_scene_destroy(self.h)
+            self.h = None
+
+    @classmethod
+    def from_arrays(cls, d):
+        """d: the fixture layout (mesh_vert_off, mesh_tri_off, verts, tris, materials, mesh_tex, tex_w, tex_h,
+        tex_off, texels, lights)."""
+        s = cls()
+        L = host()
+        tex_ids = []
+        for t in range(len(d["tex_w"])):
+            w, h, off = int(d["tex_w"][t]), int(d["tex_h"][t]), int(d["tex_off"][t])
+            px = np.ascontiguousarray(d["texels"][off:off + w * h], np.float32)
+            tex_ids.append(L.srth_scene_add_texture(s.h, w, h, _p(px)))
+        for m in range(len(d["materials"])):
+            v = np.ascontiguousarray(d["verts"][d["mesh_vert_off"][m]:d["mesh_vert_off"][m + 1]], np.float32)
+            t = np.ascontiguousarray(d["tris"][d["mesh_tri_off"][m]:d["mesh_tri_off"][m + 1]], np.uint32)
+            k = np.ascontiguousarray(d["materials"][m], np.float32)
+            tex = int(d["mesh_tex"][m])
+            L.srth_scene_add_mesh(s.h, _p(v), len(v), _p(t, _u32p), len(t), _p(k), tex_ids[tex] if tex >= 0 else -1)
+        for l in np.asarray(d["lights"], np.float32).reshape(-1, LIGHT_STRIDE):
+            _check(L.srth_scene_add_light(s.h, _p(np.ascontiguousarray(l))))
+        return s
+
+    @classmethod
+    def from_obj(cls, path, normalize=False, lights=()):
+        """loadSceneFromFile: meshes from an OBJ file plus caller-supplied lights."""
+        s = cls()
+        _check(host().srth_scene_load_obj(s.h, os.fsencode(path), int(normalize)))
+        for l in lights:
+            _check(host().srth_scene_add_light(s.h, _p(np.ascontiguousarray(l, np.float32))))
+        return s
+
+    @classmethod
+    def prebuilt(cls, scene_type, data_dir):
+        """loadScenePrebuilt(type, dataDir)."""
+        s = cls()
+        _check(host().srth_scene_load_prebuilt(s.h, int(scene_type), os.fsencode(data_dir)))
+        return s
+
+    def add_light(self, light22):
+        _check(host().srth_scene_add_light(self.h, _p(np.ascontiguousarray(light22, np.float32))))
+
+    def to_arrays(self):
+        """Back to the fixture layout (used to compare the OBJ loader with the reference loader's output)."""
+        L = host()
+        nm = L.srth_scene_num_meshes(self.h)
+        vo, to, verts, tris, mats, mtex = [0], [0], [], [], [], []
+        tw, th, toff, tex = [], [], [], []
+        off = 0
+        for m in range(nm):
+            nv, nt = C.c_int32(), C.c_int32()
+            L.srth_scene_mesh_sizes(self.h, m, C.byref(nv), C.byref(nt))
+            v = np.zeros((nv.value, 8), np.float32)
+            t = np.zeros((nt.value, 3), np.uint32)
+            k = np.zeros(8, np.float32)
+            wh = np.zeros(2, np.int32)
+            has = L.srth_scene_mesh_get(self.h, m, _p(v), _p(t, _u32p), _p(k), _p(wh, _i32p))
+            vo.append(vo[-1] + nv.value)
+            to.append(to[-1] + nt.value)
+            verts.append(v), tris.append(t), mats.append(k)
+            if has:
+                px = np.zeros((int(wh[0]) * int(wh[1]), 3), np.float32)
+                L.srth_scene_mesh_texture(self.h, m, _p(px))
+                mtex.append(len(tw))
+                tw.append(int(wh[0])), th.append(int(wh[1])), toff.append(off), tex.append(px)
+                off += len(px)
+            else:
+                mtex.append(-1)
+        nl = L.srth_scene_num_lights(self.h)
+        lights = np.zeros((nl, LIGHT_STRIDE), np.float32)
+        for i in range(nl):
+            L.srth_scene_light_get(self.h, i, _p(lights[i]))
+        return {
+            "mesh_vert_off": np.array(vo, np.uint32), "mesh_tri_off": np.array(to, np.uint32),
+            "verts": np.concatenate(verts) if verts else np.zeros((0, 8), np.float32),
+            "tris": np.concatenate(tris) if tris else np.zeros((0, 3), np.uint32),
+            "materials": np.stack(mats) if mats else np.zeros((0, 8), np.float32),
+            "mesh_tex": np.array(mtex, np.int32), "tex_w": np.array(tw, np.uint32), "tex_h": np.array(th, np.uint32),
+            "tex_off": np.array(toff, np.uint64),
+            "texels": np.concatenate(tex) if tex else np.zeros((0, 3), np.float32), "lights": lights,
+        }
+
+
+class HostBvh:
+    """BoundingVolumeHierarchy built and flattened on the host only (no GPU needed)."""
+
+    def __init__(self, scene, features=F_ACCEL):
+        self.scene = scene
+        self.h = host().srth_hostbvh_create(scene.h, features)
+        if not self.h:
+            raise SrtError(host().srth_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host().srth_hostbvh_destroy(self.h)
+            self.h = None
+
+    num_levels = property(lambda self: host().srth_hostbvh_num_levels(self.h))
+    num_leaves = property(lambda self: host().srth_hostbvh_num_leaves(self.h))
+    num_nodes = property(lambda self: host().srth_hostbvh_num_nodes(self.h))
+
+    def dump(self):
+        n = self.num_nodes
+        meta, box = np.zeros((n, 4), np.int32), np.zeros((n, 6), np.float32)
+        host().srth_hostbvh_dump(self.h, _p(meta, _i32p), _p(box))
+        return meta, box
+
+    def tri_order(self):
+        n = host().srth_hostbvh_tri_order(self.h, None)
+        out = np.zeros((n, 2), np.int32)
+        host().srth_hostbvh_tri_order(self.h, _p(out, _i32p))
+        return out
+
+    def flatten(self, bfs_levels=0):
+        sizes = np.zeros(2, np.uint32)
+        _check(host().srth_hostbvh_flatten(self.h, bfs_levels, _p(sizes, _u32p), None, None, None, None, None, None))
+        nodes = np.zeros(int(sizes[0]), NODE_DTYPE)
+        tris = np.zeros(int(sizes[1]), TRI_DTYPE)
+        attrs = np.zeros(int(sizes[1]), ATTR_DTYPE)
+        order = np.zeros(int(sizes[1]), np.uint32)
+        root_box = np.zeros(6, np.float32)
+        root_ref = np.zeros(1, np.uint32)
+        _check(host().srth_hostbvh_flatten(self.h, bfs_levels, _p(sizes, _u32p), nodes.ctypes.data, tris.ctypes.data,
+                                           attrs.ctypes.data, _p(order, _u32p), _p(root_box), _p(root_ref, _u32p)))
+        return {"nodes": nodes, "tris": tris, "attrs": attrs, "scene_order": order, "root_box": root_box,
+                "root_ref": int(root_ref[0])}
+
+
+class Bvh:
+    """BvhInterface: builds the BVH on the host, uploads the flattened scene to the current GPU."""
+
+    def __init__(self, scene, features=F_ACCEL):
+        self.scene = scene
+        self.h = host().srth_bvh_create(scene.h, features)
+        if not self.h:
+            raise SrtError(host().srth_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            host().srth_bvh_destroy(self.h)
+            self.h = None
+
+    num_levels = property(lambda self: host().srth_bvh_num_levels(self.h))
+    num_leaves = property(lambda self: host().srth_bvh_num_leaves(self.h))
+
+    def intersect(self, rays7, features):
+        """BvhInterface::intersect for many rays; returns (hits, updated rays, counters)."""
+        rays = np.ascontiguousarray(rays7, np.float32).copy()
+        hits = np.zeros(len(rays), HIT_DTYPE)
+        cnt = Counters()
+        _check(host().srth_bvh_intersect(self.h, _p(rays), len(rays), features, hits.ctypes.data, C.byref(cnt)))
+        return hits, rays, cnt.as_dict()
+
+    def final_color(self, rays7, features, max_depth=5, seed=0):
+        rays = np.ascontiguousarray(rays7, np.float32)
+        rgb = np.zeros((len(rays), 3), np.float32)
+        _check(host().srth_final_color(self.h, _p(rays), len(rays), features, max_depth, seed, _p(rgb)))
+        return rgb
+
+    def params(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0):
+        p = RenderParams()
+        p.camera = cam
+        p.features = features
+        p.samples_x, p.samples_y = nsx, nsy
+        p.max_depth = max_depth
+        p.seed = seed
+        r = rect if rect is not None else (0, 0, cam.width, cam.height)
+        p.rect[:] = list(r)
+        p.flags = flags
+        return p
+
+    def render(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0, primary=True):
+        """renderRayTracing into host arrays in Screen layout; returns rgb (+ primary hit of sample 0)."""
+        W, H = cam.width, cam.height
+        rgb = np.zeros((H, W, 3), np.float32)
+        pm = np.full((H, W), -1, np.int32)
+        pt = np.full((H, W), -1, np.int32)
+        tt = np.zeros((H, W), np.float32)
+        p = self.params(cam, features, nsx, nsy, max_depth, seed, rect, flags)
+        o = Output()
+        o.rgb = rgb.ctypes.data
+        if primary:
+            o.prim_mesh, o.prim_tri, o.prim_t = pm.ctypes.data, pt.ctypes.data, tt.ctypes.data
+        o.out_width, o.out_height, o.x0, o.y0, o.on_device = W, H, 0, 0, 0
+        self.read_counters(reset=True)
+        _check(host().srth_render(self.h, C.byref(p), C.byref(o), None))
+        return {"rgb": rgb, "mesh": pm, "tri": pt, "t": tt, "counters": self.read_counters(reset=True)}
+
+    def render_device(self, params, rgb_ptr, out_w, out_h, x0, y0, stream=None):
+        """Enqueue one rectangle into a device buffer (tile-local or whole frame); does not synchronize."""
+        o = Output()
+        o.rgb = rgb_ptr
+        o.out_width, o.out_height, o.x0, o.y0, o.on_device = out_w, out_h, x0, y0, 1
+        _check(host().srth_render(self.h, C.byref(params), C.byref(o), stream))
+
+    def read_counters(self, stream=None, reset=False):
+        c = Counters()
+        _check(host().srth_read_counters(self.h, stream, C.byref(c), int(reset)))
+        return c.as_dict()
+
+    def last_kernel_ms(self):
+        ms = np.zeros(4, np.float32)
+        _check(host().srth_last_kernel_ms(self.h, _p(ms)))
+        return {"trace_primary": float(ms[0]), "trace_secondary": float(ms[1]), "shade": float(ms[2]), "resolve": float(ms[3])}
+
+    def synchronize(self, stream=None):
+        _check(host().srth_synchronize(self.h, stream))
+
+
+def make_camera(width, height, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20, 20, 0)):
+    """Trackball set up as the reference's CLI does; defaults are its CameraConfig defaults (src/config.h:16-21)."""
+    cam = Camera()
+    la, rd = np.array(look_at, np.float32), np.array(rot_deg, np.float32)
+    _check(host().srth_camera_make(fovy_deg, dist, _p(la), _p(rd), width, height, C.byref(cam)))
+    return cam
+
+
+def generate_rays(cam, ndc):
+    ndc = np.ascontiguousarray(ndc, np.float32).reshape(-1, 2)
+    rays = np.zeros((len(ndc), 7), np.float32)
+    _check(host().srth_generate_rays(C.byref(cam), _p(ndc), len(ndc), _p(rays)))
+    return rays
+
+
+def write_bmp(path, rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    _check(host().srth_write_bmp(os.fsencode(path), _p(rgb), rgb.shape[1], rgb.shape[0]))

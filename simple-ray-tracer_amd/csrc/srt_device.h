@@ -1,0 +1,166 @@
+/*
+ * srt_device.h -- device-side arithmetic of the ray tracer's hot path for gfx950 (wave64).
+ *
+ * Every function performs the reference's float operations in the reference's order; the translation unit
+ * must be compiled with -ffp-contract=off (hipcc contracts a*b+c into an FMA by default, the reference's
+ * x86-64 build does not) and with hipcc's default correctly-rounded division and square root.
+ * std::min / std::max / glm::min / glm::max are (b < a) ? b : a and (a < b) ? b : a: NaN handling differs
+ * from fminf / fmaxf, so they are spelled out.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srt_hip.h"
+
+#define SRT_FLT_MAX 3.402823466e+38f
+#define SRT_BLOCK 256
+
+struct f3 {
+    float x, y, z;
+};
+struct f2 {
+    float x, y;
+};
+
+#define SRT_DI __device__ __forceinline__
+
+SRT_DI f3 mk3(float x, float y, float z)
+{
+    f3 r;
+    r.x = x, r.y = y, r.z = z;
+    return r;
+}
+SRT_DI f3 xyz(float4 q) { return mk3(q.x, q.y, q.z); }
+SRT_DI f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SRT_DI f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SRT_DI f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+SRT_DI f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+SRT_DI f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+SRT_DI f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+SRT_DI f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+/* glm dot / cross / length / normalize, scalar paths (glm/detail/func_geometric.inl:8-14,48-55,68-90) */
+SRT_DI float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SRT_DI f3 cross3(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+SRT_DI float length3(f3 v) { return __builtin_sqrtf(dot3(v, v)); }
+SRT_DI f3 normalize3(f3 v) { return v * (1.0f / __builtin_sqrtf(dot3(v, v))); }
+SRT_DI float min_std(float a, float b) { return (b < a) ? b : a; }
+SRT_DI float max_std(float a, float b) { return (a < b) ? b : a; }
+SRT_DI float clamp01(float x) { return min_std(max_std(x, 0.0f), 1.0f); }
+
+/* Ray/box slab test, reference src/intersect.cpp:134-160, in the form the traversal needs.
+ * Returns whether the test passes; val is what getClosestIntersectionWithBox
+ * (src/bounding_volume_hierarchy.cpp:305-310) returns: T on a failure, t_out when the origin is inside or
+ * on the box (t_in <= 0), else t_in.  inside tells the two passing cases apart. */
+SRT_DI bool slab_test(const float lo[3], const float hi[3], f3 o, f3 d, float T, float& val, bool& inside)
+{
+    float txmin = (lo[0] - o.x) / d.x;
+    float tymin = (lo[1] - o.y) / d.y;
+    float tzmin = (lo[2] - o.z) / d.z;
+    float txmax = (hi[0] - o.x) / d.x;
+    float tymax = (hi[1] - o.y) / d.y;
+    float tzmax = (hi[2] - o.z) / d.z;
+    float tinx = min_std(txmin, txmax), toutx = max_std(txmin, txmax);
+    float tiny = min_std(tymin, tymax), touty = max_std(tymin, tymax);
+    float tinz = min_std(tzmin, tzmax), toutz = max_std(tzmin, tzmax);
+    float tin = max_std(tinx, max_std(tiny, tinz));
+    float tout = min_std(toutx, min_std(touty, toutz));
+    inside = false;
+    if (tin > tout || tout < 0 || tin > T) {
+        val = T;
+        return false;
+    }
+    val = tin;
+    if (tin <= 0) {
+        val = tout;
+        inside = true;
+    }
+    return true;
+}
+
+/* Ray/triangle test, reference src/intersect.cpp:13-77, on a precomputed srt_tri record (six float4).
+ * On acceptance T becomes the new distance. */
+SRT_DI bool tri_test(const float4* __restrict__ rec, f3 o, f3 d, float& T)
+{
+    const float4 q0 = rec[0];
+    const f3 n = xyz(q0);
+    const float D = q0.w;
+    const float dn = dot3(d, n);
+    const float on = dot3(o, n);
+    if (dn == 0.0f || on == D)
+        return false;
+    const float nt = (D - on) / dn;
+    if (nt < 0)
+        return false;
+    if (!(nt <= T))
+        return false;
+    const f3 p = o + d * nt;
+    const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+    const f3 v0 = xyz(q1), v1 = xyz(q2), v2 = mk3(q3.x, q3.y, q3.z);
+    const f3 c0 = mk3(q3.w, q4.x, q4.y), c1 = mk3(q4.z, q4.w, q5.x), c2 = mk3(q5.y, q5.z, q5.w);
+    /* sameSide(p, v0, v1, v2) && sameSide(p, v1, v0, v2) && sameSide(p, v2, v0, v1) */
+    if (!(dot3(cross3(v2 - v1, p - v1), c0) >= 0))
+        return false;
+    if (!(dot3(cross3(v2 - v0, p - v0), c1) >= 0))
+        return false;
+    if (!(dot3(cross3(v1 - v0, p - v0), c2) >= 0))
+        return false;
+    T = nt;
+    return true;
+}
+
+/* computeBarycentricCoord, reference src/interpolate.cpp:4-15 */
+SRT_DI f3 barycentric3(f3 v0, f3 v1, f3 v2, f3 p)
+{
+    f3 d0 = v1 - v0, d1 = v2 - v1, d2 = v0 - v2;
+    float a0 = length3(cross3(d1, v1 - p));
+    float a1 = length3(cross3(d2, v2 - p));
+    float a2 = length3(cross3(d0, v0 - p));
+    float sum = a0 + a1 + a2;
+    if (sum == 0)
+        return mk3(1, 0, 0);
+    return mk3(a0 / sum, a1 / sum, a2 / sum);
+}
+
+/* computeShading, reference src/shading.cpp:6-30 (powf is the only operation that is not correctly
+ * rounded on either side; it only reaches colours) */
+SRT_DI f3 compute_shading(f3 lightPos, f3 lightCol, f3 ro, f3 rd, float rt, f3 hitNormal, f3 kd, f3 ks, float shininess)
+{
+    f3 rayPosition = ro + rd * rt;
+    f3 L = normalize3(lightPos - rayPosition);
+    f3 N = normalize3(hitNormal);
+    f3 camV = rayPosition - ro;
+    f3 R = ((2.0f * dot3(L, N)) * N) - L;
+    f3 lambert = (lightCol * kd) * clamp01(dot3(N, L));
+    f3 spec = (lightCol * ks) * powf(clamp01(dot3(R, normalize3(camV))), shininess);
+    return lambert + spec;
+}
+
+/* Trackball::generateRay, reference framework/src/trackball.cpp:101-110; quaternion * vector as
+ * glm/detail/type_quat.inl:347-354 */
+SRT_DI f3 camera_dir(const srt_camera& cam, float nx, float ny)
+{
+    f3 d = normalize3(mk3(-nx * cam.half_w, ny * cam.half_h, 1.0f));
+    f3 q = mk3(cam.quat[1], cam.quat[2], cam.quat[3]);
+    f3 uv = cross3(q, d);
+    f3 uuv = cross3(q, uv);
+    return d + ((uv * cam.quat[0]) + uuv) * 2.0f;
+}
+
+/* Counter-based uniform sample in [0,1) for the soft-shadow samplers (the reference uses libc rand()). */
+SRT_DI uint32_t mix32(uint32_t h, uint32_t k)
+{
+    h ^= k;
+    h *= 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    h *= 0xC2B2AE3Du;
+    h ^= h >> 16;
+    return h;
+}
+SRT_DI float rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim)
+{
+    uint32_t h = mix32(mix32(mix32(mix32(mix32(seed, path), depth), light), sample), dim);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}

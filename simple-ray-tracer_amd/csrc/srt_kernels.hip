@@ -1,0 +1,1228 @@
+/*
+ * srt_kernels.hip -- hand-written gfx950 kernels and the C ABI of libsrt_hip.so (include/srt_hip.h).
+ *
+ * One frame rectangle is rendered as a wavefront pipeline, all launches stream ordered, no host round trip:
+ *
+ *   trace_primary   one lane per pixel sample: camera ray (Trackball::generateRay) + BVH query; lanes that
+ *                   hit are compacted (wave ballot + one atomic per wave) into the hit queue
+ *   shade           one lane per queued hit: hit attributes, light loop with the shadow-ray BVH queries
+ *                   traced inline by the same traversal routine, accumulation into the sample's slot,
+ *                   reflection ray compacted into the next path queue
+ *   trace_secondary one lane per queued path ray: BVH query, hits compacted into the hit queue
+ *   ... shade / trace_secondary repeat up to max_depth times ...
+ *   resolve         one lane per pixel: sum of the pixel's samples in the reference's loop order, division,
+ *                   store at Screen::setPixel's position
+ *
+ * Queue kernels run as a persistent grid that strides over the queue; the queue length is read from
+ * device memory.  A sample owns its accumulator slot, so no floating-point atomics are used and a frame
+ * is bit-reproducible run to run.
+ *
+ * Traversal (BoundingVolumeHierarchy::intersect, reference src/bounding_volume_hierarchy.cpp:316-393).
+ * The reference keeps a LIFO of node indices, tests a child's box against the running closest distance C
+ * when the parent is visited (push if boxval < C) and again when the node is popped (skip if boxval > C),
+ * pushes left then right, and never sorts children.  The same visiting order is produced here with a
+ * per-lane stack in LDS that only ever holds pending LEFT siblings:
+ *   - the right child is popped immediately after being pushed, with the same T and C, so its pop test
+ *     repeats its push test and always passes: the lane simply continues into it (likewise a lone child);
+ *   - for a pending left sibling the pop test needs boxval under the CURRENT T.  With t_in / t_out of the
+ *     box fixed, boxval is T for a failed slab test, t_out when the origin is inside, else t_in, and after
+ *     the first accepted hit C == T.  A node that was pushed is therefore skipped at pop exactly when
+ *     it is an origin-inside node with t_out > C (reference rule), or - with SRT_F_MISS_CULL - when its
+ *     stored boxval exceeds C.  Both are `v > C` on a float v stored next to the node reference
+ *     (v = -1 for entries the reference never skips), so a pop costs one 8-byte LDS read and no box test.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "srt_device.h"
+
+/* ------------------------------------------------------------------------------------------ device views */
+
+struct SceneDev {
+    const float4* nodes; /* 4 float4 per srt_node */
+    const float4* tris;  /* 6 float4 per srt_tri */
+    const float4* attrs; /* 4 float4 per srt_tri_attr */
+    const uint32_t* scene_order;
+    const srt_material* materials;
+    const srt_texture* textures;
+    const float* texels;
+    const srt_light* lights;
+    uint32_t n_nodes, n_tris, n_materials, n_textures, n_lights;
+    uint32_t root_ref;
+    float root_lo[3], root_hi[3];
+    uint64_t n_texels;
+};
+
+struct DevCounters {
+    unsigned long long path_rays, shadow_rays, shaded_hits, inner_visits, tri_tests, box_tests;
+};
+
+struct Stats {
+    uint32_t inner, tri, box;
+};
+
+/* A queued path ray is three float4: (o.xyz, d.x) (d.y, d.z, thr.x, thr.y) (thr.z, sample, -, -). */
+
+struct HitQ {
+    uint32_t* slot; /* primary: sample index; secondary: index into the path queue */
+    float* t;
+    uint32_t* tri; /* leaf-order triangle position */
+};
+
+struct RenderDev {
+    srt_camera cam;
+    uint32_t features;
+    int32_t nsx, nsy, S;
+    int32_t max_depth;
+    uint32_t seed;
+    int32_t x0, y0, tw, th; /* rectangle origin and size */
+    uint32_t n_samples;     /* tw * th * S */
+    float* out_rgb;
+    int32_t* out_mesh;
+    int32_t* out_tri;
+    float* out_t;
+    int32_t out_w, out_h, out_x0, out_y0;
+    const float* custom_rays; /* when set, sample s is the caller's ray s (7 floats) instead of a camera ray */
+};
+
+/* ------------------------------------------------------------------------------------------ traversal */
+
+SRT_DI uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+/* Adds per-lane tallies to the device totals: one reduction per wave, one atomic per field. */
+SRT_DI void flush_counters(DevCounters* c, uint32_t path, uint32_t shadow, uint32_t shaded, const Stats& st)
+{
+    uint32_t a = wave_sum(path), b = wave_sum(shadow), s = wave_sum(shaded);
+    uint32_t i = wave_sum(st.inner), t = wave_sum(st.tri), x = wave_sum(st.box);
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&c->path_rays, (unsigned long long)a);
+        if (b) atomicAdd(&c->shadow_rays, (unsigned long long)b);
+        if (s) atomicAdd(&c->shaded_hits, (unsigned long long)s);
+        if (i) atomicAdd(&c->inner_visits, (unsigned long long)i);
+        if (t) atomicAdd(&c->tri_tests, (unsigned long long)t);
+        if (x) atomicAdd(&c->box_tests, (unsigned long long)x);
+    }
+}
+
+/* The accel-structure-off branch (reference :319-332): every triangle of every mesh, in scene order. */
+template <bool COUNT>
+SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, Stats& st)
+{
+    bool any = false;
+    for (uint32_t k = 0; k < sc.n_tris; ++k) {
+        uint32_t pos = sc.scene_order[k];
+        if (COUNT)
+            st.tri += 1;
+        if (tri_test(sc.tris + 6ull * pos, o, d, T)) {
+            any = true;
+            hitTri = pos;
+        }
+    }
+    return any;
+}
+
+/* BVH query.  stk points at this lane's column of the block's LDS stack (entry k at stk[k * SRT_BLOCK]).
+ * Returns whether anything was accepted; T is the final Ray::t, hitTri the last accepted triangle. */
+template <bool CULL, bool COUNT>
+SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
+{
+    float C = SRT_FLT_MAX;
+    float val;
+    bool inside;
+    bool pass = slab_test(sc.root_lo, sc.root_hi, o, d, T, val, inside);
+    if (COUNT)
+        st.box += 1;
+    if (!(val < C && (pass || !CULL)))
+        return false;
+    uint32_t cur = sc.root_ref;
+    int sp = 0;
+    for (;;) {
+        bool need_pop;
+        if (cur & SRT_LEAF_FLAG) {
+            const uint32_t first = cur & 0x00FFFFFFu;
+            const uint32_t cnt = (cur >> 24) & 0x7Fu;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                if (COUNT)
+                    st.tri += 1;
+                if (tri_test(sc.tris + 6ull * (first + k), o, d, T)) {
+                    C = min_std(C, T);
+                    hitTri = first + k;
+                }
+            }
+            need_pop = true;
+        } else {
+            if (COUNT) {
+                st.inner += 1;
+                st.box += 2;
+            }
+            const float4* nd = sc.nodes + 4ull * cur;
+            const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+            const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+            const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
+            const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
+            float lval, rval;
+            bool lin, rin;
+            const bool lpass = slab_test(llo, lhi, o, d, T, lval, lin);
+            const bool rpass = slab_test(rlo, rhi, o, d, T, rval, rin);
+            const bool pushL = lval < C && (lpass || !CULL);
+            const bool pushR = rval < C && (rpass || !CULL);
+            need_pop = false;
+            if (pushL && pushR) {
+                /* pending left sibling; v as described at the top of the file */
+                const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
+                stk[sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
+                ++sp;
+                cur = right;
+            } else if (pushR) {
+                cur = right;
+            } else if (pushL) {
+                cur = left;
+            } else {
+                need_pop = true;
+            }
+        }
+        if (need_pop) {
+            bool got = false;
+            while (sp > 0) {
+                --sp;
+                const uint2 en = stk[sp * SRT_BLOCK];
+                if (!(__uint_as_float(en.y) > C)) {
+                    cur = en.x;
+                    got = true;
+                    break;
+                }
+            }
+            if (!got)
+                break;
+        }
+    }
+    return C != SRT_FLT_MAX;
+}
+
+template <bool CULL, bool COUNT>
+SRT_DI bool bvh_query(const SceneDev& sc, uint32_t features, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
+{
+    hitTri = 0xFFFFFFFFu;
+    if (features & SRT_F_ACCEL)
+        return traverse<CULL, COUNT>(sc, o, d, T, hitTri, stk, st);
+    return traverse_linear<COUNT>(sc, o, d, T, hitTri, st);
+}
+
+/* ------------------------------------------------------------------------------------------ hit attributes */
+
+struct Surface {
+    f3 normal, bary, kd, ks;
+    f2 uv;
+    float shininess;
+    uint32_t mesh, tri;
+};
+
+/* acquireTexel, reference src/texture.cpp:5-15.  The reference does not bound the index; the linear index
+ * is clamped into the image here, identical wherever the reference's behaviour is defined. */
+SRT_DI f3 fetch_texel(const SceneDev& sc, int tex, f2 uv)
+{
+    const srt_texture tx = sc.textures[tex];
+    int i = (int)(uv.x * (float)tx.width);
+    int j = (int)((float)tx.height - uv.y * (float)tx.height);
+    long long idx = (long long)j * (long long)tx.width + i;
+    long long last = (long long)tx.width * tx.height - 1;
+    idx = idx < 0 ? 0 : (idx > last ? last : idx);
+    const float* p = sc.texels + 3ull * (tx.offset + (unsigned long long)idx);
+    return mk3(p[0], p[1], p[2]);
+}
+
+/* What intersectWithLeafTriangle leaves in HitInfo for the accepted triangle (reference
+ * src/bounding_volume_hierarchy.cpp:262-303).  bary stays 0 without normal interpolation (the reference
+ * reads it uninitialised when only texture mapping is on). */
+SRT_DI void surface_at(const SceneDev& sc, uint32_t features, f3 o, f3 d, float T, uint32_t pos, Surface& s)
+{
+    const float4* rec = sc.tris + 6ull * pos;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+    const f3 v0 = xyz(q1), v1 = xyz(q2), v2 = xyz(q3);
+    s.mesh = __float_as_uint(q1.w);
+    s.tri = __float_as_uint(q2.w);
+    /* normalize(cross(v1 - v0, v2 - v0)) is the stored plane normal: same operations, and an accepted
+     * triangle cannot be the zero-area case */
+    s.normal = xyz(q0);
+    s.bary = mk3(0, 0, 0);
+    s.uv.x = 0, s.uv.y = 0;
+    const srt_material m = sc.materials[s.mesh];
+    s.kd = mk3(m.kd[0], m.kd[1], m.kd[2]);
+    s.ks = mk3(m.ks[0], m.ks[1], m.ks[2]);
+    s.shininess = m.shininess;
+    const f3 p = o + d * T;
+    const float4* at = sc.attrs + 4ull * pos;
+    if (features & SRT_F_NORMAL_INTERP) {
+        s.bary = barycentric3(v0, v1, v2, p);
+        const float4 a0 = at[0], a1 = at[1], a2 = at[2];
+        const f3 n0 = mk3(a0.x, a0.y, a0.z), n1 = mk3(a0.w, a1.x, a1.y), n2 = mk3(a1.z, a1.w, a2.x);
+        s.normal = normalize3(((s.bary.x * n0) + (s.bary.y * n1)) + (s.bary.z * n2));
+    }
+    {
+        const f3 toCam = normalize3(o - p);
+        if (dot3(s.normal, toCam) <= 0)
+            s.normal = -s.normal;
+    }
+    if (features & SRT_F_TEXTURE) {
+        const float4 a2 = at[2], a3 = at[3];
+        const f2 t0 = { a2.y, a2.z }, t1 = { a2.w, a3.x }, t2 = { a3.y, a3.z };
+        s.uv.x = (t0.x * s.bary.x + t1.x * s.bary.y) + t2.x * s.bary.z;
+        s.uv.y = (t0.y * s.bary.x + t1.y * s.bary.y) + t2.y * s.bary.z;
+        if (m.texture >= 0)
+            s.kd = fetch_texel(sc, m.texture, s.uv);
+    }
+}
+
+/* testVisibilityLightSample, reference src/light.cpp:43-74 */
+template <bool CULL, bool COUNT>
+SRT_DI float visibility(const SceneDev& sc, uint32_t features, f3 samplePos, f3 ip, uint2* stk, Stats& st, uint32_t& nShadow)
+{
+    if (!(features & (SRT_F_HARD_SHADOW | SRT_F_SOFT_SHADOW)))
+        return 1.0f;
+    if (ip.x == samplePos.x && ip.y == samplePos.y && ip.z == samplePos.z)
+        return 1.0f;
+    f3 dir = samplePos - ip;
+    f3 org = ip + normalize3(dir) * 0.001f;
+    float T = 1.0f;
+    uint32_t tri;
+    nShadow += 1;
+    /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
+    if (bvh_query<CULL, COUNT>(sc, features, org, dir, T, tri, stk, st) && T < 0.99f)
+        return 0.0f;
+    return 1.0f;
+}
+
+/* computeLightContribution with its samplers, reference src/light.cpp:14-39,109-166 */
+template <bool CULL, bool COUNT>
+SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t seed, uint32_t path, uint32_t depth, f3 o,
+                             f3 d, float T, const Surface& s, uint2* stk, Stats& st, uint32_t& nShadow)
+{
+    if (!(features & SRT_F_SHADING))
+        return s.kd;
+    f3 res = mk3(0, 0, 0);
+    const f3 ip = o + d * T;
+    for (uint32_t li = 0; li < sc.n_lights; ++li) {
+        const srt_light* L = sc.lights + li;
+        const uint32_t type = L->type;
+        if (type == 0) {
+            const f3 pos = mk3(L->f[0], L->f[1], L->f[2]), col = mk3(L->f[3], L->f[4], L->f[5]);
+            const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
+            if (features & SRT_F_HARD_SHADOW)
+                res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
+            else
+                res = res + sh;
+        } else if (type == 1) {
+            if (!(features & SRT_F_SOFT_SHADOW))
+                continue;
+            const f3 e0 = mk3(L->f[0], L->f[1], L->f[2]), e1 = mk3(L->f[3], L->f[4], L->f[5]);
+            const f3 c0 = mk3(L->f[6], L->f[7], L->f[8]), c1 = mk3(L->f[9], L->f[10], L->f[11]);
+            const int N = 100;
+            for (int t = 0; t < N; ++t) {
+                const float r = rand01(seed, path, depth, li, (uint32_t)t, 0);
+                const float a = ((float)t + r) / (float)N;
+                const f3 pos = mk3(e0.x * a + e1.x * (1 - a), e0.y * a + e1.y * (1 - a), e0.z * a + e1.z * (1 - a));
+                const f3 col = mk3(c0.x * a + c1.x * (1 - a), c0.y * a + c1.y * (1 - a), c0.z * a + c1.z * (1 - a));
+                const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / (float)N;
+                res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
+            }
+        } else {
+            if (!(features & SRT_F_SOFT_SHADOW))
+                continue;
+            const f3 p0 = mk3(L->f[0], L->f[1], L->f[2]), e01 = mk3(L->f[3], L->f[4], L->f[5]);
+            const f3 e02 = mk3(L->f[6], L->f[7], L->f[8]);
+            const f3 c0 = mk3(L->f[9], L->f[10], L->f[11]), c1 = mk3(L->f[12], L->f[13], L->f[14]);
+            const f3 c2 = mk3(L->f[15], L->f[16], L->f[17]), c3 = mk3(L->f[18], L->f[19], L->f[20]);
+            const int N = 10;
+            for (int i = 0; i < N; ++i) {
+                for (int j = 0; j < N; ++j) {
+                    const float r1 = rand01(seed, path, depth, li, (uint32_t)(i * N + j), 0);
+                    const float r2 = rand01(seed, path, depth, li, (uint32_t)(i * N + j), 1);
+                    const float x = ((float)i + r1) / (float)N;
+                    const float y = ((float)j + r2) / (float)N;
+                    const f3 pos = (p0 + (x * e01)) + (y * e02);
+                    const f3 col = ((((c0 * (1 - x)) * (1 - y)) + ((c1 * x) * (1 - y))) + ((c2 * y) * (1 - x))) + ((c3 * x) * y);
+                    const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / (float)(N * N);
+                    res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
+                }
+            }
+        }
+    }
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------ frame kernels */
+
+/* Sample index inside the rectangle -> pixel and sub-sample; consecutive samples of a pixel are adjacent. */
+SRT_DI void sample_decode(const RenderDev& rp, uint32_t s, int& px, int& py, int& sub)
+{
+    const uint32_t p = s / (uint32_t)rp.S;
+    sub = (int)(s - p * (uint32_t)rp.S);
+    py = rp.y0 + (int)(p / (uint32_t)rp.tw);
+    px = rp.x0 + (int)(p % (uint32_t)rp.tw);
+}
+
+/* Normalized pixel position of a sample, reference src/render.cpp:190-193 (one ray per pixel) and
+ * :200-209 (n x n grid; the reference's random offset is below 4.7e-10 and vanishes in the float sums). */
+SRT_DI void sample_ndc(const RenderDev& rp, int px, int py, int sub, float& nx, float& ny)
+{
+    const float W = (float)rp.cam.width, H = (float)rp.cam.height;
+    if (rp.features & SRT_F_MULTISAMPLE) {
+        const int i = sub / rp.nsy, j = sub - i * rp.nsy;
+        const float a = ((float)i + 0.0f) / (float)rp.nsx + (float)px;
+        const float b = ((float)j + 0.0f) / (float)rp.nsy + (float)py;
+        nx = a / W * 2.0f - 1.0f;
+        ny = b / H * 2.0f - 1.0f;
+    } else {
+        nx = (float)px / W * 2.0f - 1.0f;
+        ny = (float)py / H * 2.0f - 1.0f;
+    }
+}
+
+SRT_DI long long out_index(const RenderDev& rp, int px, int py)
+{
+    return (long long)(rp.out_h - 1 - (py - rp.out_y0)) * rp.out_w + (px - rp.out_x0);
+}
+
+/* Primary ray of sample s: a camera ray, or the caller's own ray for srt_final_color_batch. */
+SRT_DI void primary_ray(const RenderDev& rp, uint32_t s, f3& o, f3& d, float& T, int& px, int& py, int& sub)
+{
+    if (rp.custom_rays) {
+        const float* r = rp.custom_rays + 7ull * s;
+        o = mk3(r[0], r[1], r[2]);
+        d = mk3(r[3], r[4], r[5]);
+        T = r[6];
+        px = (int)s, py = 0, sub = 0;
+        return;
+    }
+    sample_decode(rp, s, px, py, sub);
+    float nx, ny;
+    sample_ndc(rp, px, py, sub, nx, ny);
+    o = mk3(rp.cam.origin[0], rp.cam.origin[1], rp.cam.origin[2]);
+    d = camera_dir(rp.cam, nx, ny);
+    T = SRT_FLT_MAX;
+}
+
+/* Appends the lanes with want == true to a queue: one atomic per wave, slots in lane order. */
+SRT_DI uint32_t queue_slot(bool want, uint32_t* count)
+{
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0)
+        return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader)
+        base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + rank;
+}
+
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, RenderDev rp, HitQ hq, uint32_t* hq_count, DevCounters* cnt)
+{
+    extern __shared__ uint2 lds_stack[];
+    uint2* stk = lds_stack + threadIdx.x;
+    Stats st = { 0, 0, 0 };
+    uint32_t nPath = 0;
+    const uint32_t stride = gridDim.x * SRT_BLOCK;
+    for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < rp.n_samples; base += stride) {
+        const uint32_t s = base + (threadIdx.x & 63u);
+        const bool active = s < rp.n_samples;
+        bool hit = false;
+        float T = SRT_FLT_MAX;
+        uint32_t tri = 0xFFFFFFFFu;
+        int px = 0, py = 0, sub = 0;
+        if (active) {
+            f3 o, d;
+            primary_ray(rp, s, o, d, T, px, py, sub);
+            nPath += 1;
+            hit = bvh_query<CULL, COUNT>(sc, rp.features, o, d, T, tri, stk, st);
+            if (sub == 0 && (rp.out_mesh || rp.out_tri || rp.out_t)) {
+                const long long oi = out_index(rp, px, py);
+                int mesh = -1, ti = -1;
+                if (hit) {
+                    mesh = (int)__float_as_uint(sc.tris[6ull * tri + 1].w);
+                    ti = (int)__float_as_uint(sc.tris[6ull * tri + 2].w);
+                }
+                if (rp.out_mesh) rp.out_mesh[oi] = mesh;
+                if (rp.out_tri) rp.out_tri[oi] = ti;
+                if (rp.out_t) rp.out_t[oi] = T;
+            }
+        }
+        const uint32_t q = queue_slot(hit, hq_count);
+        if (hit) {
+            hq.slot[q] = s;
+            hq.t[q] = T;
+            hq.tri[q] = tri;
+        }
+    }
+    flush_counters(cnt, nPath, 0, 0, st);
+}
+
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint32_t features, const float4* paths, const uint32_t* n_paths,
+                                                                 HitQ hq, uint32_t* hq_count, DevCounters* cnt)
+{
+    extern __shared__ uint2 lds_stack[];
+    uint2* stk = lds_stack + threadIdx.x;
+    Stats st = { 0, 0, 0 };
+    uint32_t nPath = 0;
+    const uint32_t n = *n_paths;
+    const uint32_t stride = gridDim.x * SRT_BLOCK;
+    for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + (threadIdx.x & 63u);
+        bool hit = false;
+        float T = SRT_FLT_MAX;
+        uint32_t tri = 0xFFFFFFFFu;
+        if (i < n) {
+            const float4 a = paths[3ull * i], b = paths[3ull * i + 1];
+            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            nPath += 1;
+            hit = bvh_query<CULL, COUNT>(sc, features, o, d, T, tri, stk, st);
+        }
+        const uint32_t q = queue_slot(hit, hq_count);
+        if (hit) {
+            hq.slot[q] = i;
+            hq.t[q] = T;
+            hq.tri[q] = tri;
+        }
+    }
+    flush_counters(cnt, nPath, 0, 0, st);
+}
+
+/* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).  The
+ * reference's Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is accumulated front to back as
+ * Lo_0 + (ks_0) * Lo_1 + (ks_0 * ks_1) * Lo_2 + ...; identical for paths of at most one bounce. */
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
+                                                       const float4* cur_paths, float4* next_paths, uint32_t* next_count, float* acc,
+                                                       DevCounters* cnt)
+{
+    extern __shared__ uint2 lds_stack[];
+    uint2* stk = lds_stack + threadIdx.x;
+    Stats st = { 0, 0, 0 };
+    uint32_t nShadow = 0, nShaded = 0;
+    const uint32_t n = *hq_count;
+    const uint32_t stride = gridDim.x * SRT_BLOCK;
+    for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t h = base + (threadIdx.x & 63u);
+        bool spawn = false;
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), nthr = mk3(0, 0, 0);
+        uint32_t sample = 0;
+        if (h < n) {
+            const uint32_t slot = hq.slot[h];
+            const float T = hq.t[h];
+            const uint32_t tri = hq.tri[h];
+            f3 o, d, thr;
+            int px, py, sub;
+            if (depth == 0) {
+                sample = slot;
+                float T0;
+                primary_ray(rp, sample, o, d, T0, px, py, sub);
+                thr = mk3(1, 1, 1);
+            } else {
+                const float4 a = cur_paths[3ull * slot], b = cur_paths[3ull * slot + 1], c = cur_paths[3ull * slot + 2];
+                o = mk3(a.x, a.y, a.z);
+                d = mk3(a.w, b.x, b.y);
+                thr = mk3(b.z, b.w, c.x);
+                sample = __float_as_uint(c.y);
+                if (rp.custom_rays)
+                    px = (int)sample, py = 0, sub = 0;
+                else
+                    sample_decode(rp, sample, px, py, sub);
+            }
+            Surface sf;
+            surface_at(sc, rp.features, o, d, T, tri, sf);
+            nShaded += 1;
+            /* sampler key: frame-global sample number, so a frame does not depend on how it is cut into rectangles */
+            const uint32_t path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
+            const f3 Lo = light_contribution<CULL, COUNT>(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, stk, st, nShadow);
+            float* a3 = acc + 3ull * sample;
+            if (depth == 0) {
+                a3[0] = Lo.x, a3[1] = Lo.y, a3[2] = Lo.z;
+            } else {
+                a3[0] = a3[0] + thr.x * Lo.x;
+                a3[1] = a3[1] + thr.y * Lo.y;
+                a3[2] = a3[2] + thr.z * Lo.z;
+            }
+            if ((rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f)) {
+                /* computeReflectionRay, reference src/shading.cpp:33-51; offset = float(pow(10, -5)) */
+                const float offset = 9.99999975e-06f;
+                const f3 dn = normalize3(d);
+                const f3 nn = normalize3(sf.normal);
+                rd = dn - ((2.0f * dot3(dn, nn)) * nn);
+                ro = (o + d * T) + (offset * rd);
+                nthr = thr * sf.ks;
+                spawn = true;
+            }
+        }
+        const uint32_t q = queue_slot(spawn, next_count);
+        if (spawn) {
+            next_paths[3ull * q] = make_float4(ro.x, ro.y, ro.z, rd.x);
+            next_paths[3ull * q + 1] = make_float4(rd.y, rd.z, nthr.x, nthr.y);
+            next_paths[3ull * q + 2] = make_float4(nthr.z, __uint_as_float(sample), 0.0f, 0.0f);
+        }
+    }
+    flush_counters(cnt, 0, nShadow, nShaded, st);
+}
+
+/* Pixel value from its samples (reference src/render.cpp:213-217) stored at Screen::setPixel's position. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float* acc)
+{
+    const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
+    for (uint32_t p = blockIdx.x * SRT_BLOCK + threadIdx.x; p < n_px; p += gridDim.x * SRT_BLOCK) {
+        const int py = rp.y0 + (int)(p / (uint32_t)rp.tw), px = rp.x0 + (int)(p % (uint32_t)rp.tw);
+        f3 c = mk3(0, 0, 0);
+        if (rp.features & SRT_F_MULTISAMPLE) {
+            for (int s = 0; s < rp.S; ++s) {
+                const float* a = acc + 3ull * ((unsigned long long)p * rp.S + s);
+                c = c + mk3(a[0], a[1], a[2]);
+            }
+            c = c / (float)rp.S;
+        } else {
+            c = mk3(acc[3ull * p], acc[3ull * p + 1], acc[3ull * p + 2]);
+        }
+        float* o = rp.out_rgb + 3 * out_index(rp, px, py);
+        o[0] = c.x, o[1] = c.y, o[2] = c.z;
+    }
+}
+
+template <bool CULL>
+__global__ __launch_bounds__(SRT_BLOCK) void k_intersect_batch(SceneDev sc, float* rays7, long long n, uint32_t features, srt_hit* hits,
+                                                                 DevCounters* cnt)
+{
+    extern __shared__ uint2 lds_stack[];
+    uint2* stk = lds_stack + threadIdx.x;
+    Stats st = { 0, 0, 0 };
+    uint32_t nPath = 0;
+    const long long stride = (long long)gridDim.x * SRT_BLOCK;
+    for (long long i = (long long)blockIdx.x * SRT_BLOCK + threadIdx.x; i < n; i += stride) {
+        float* r = rays7 + 7 * i;
+        const f3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]);
+        float T = r[6];
+        uint32_t tri;
+        nPath += 1;
+        const bool hit = bvh_query<CULL, true>(sc, features, o, d, T, tri, stk, st);
+        srt_hit h;
+        h.hit = hit;
+        h.t = T;
+        h.mesh = -1, h.tri = -1;
+        h.normal[0] = h.normal[1] = h.normal[2] = 0;
+        h.bary[0] = h.bary[1] = h.bary[2] = 0;
+        h.uv[0] = h.uv[1] = 0;
+        h.kd[0] = h.kd[1] = h.kd[2] = 0;
+        if (hit) {
+            Surface sf;
+            surface_at(sc, features, o, d, T, tri, sf);
+            h.mesh = (int)sf.mesh, h.tri = (int)sf.tri;
+            h.normal[0] = sf.normal.x, h.normal[1] = sf.normal.y, h.normal[2] = sf.normal.z;
+            h.bary[0] = sf.bary.x, h.bary[1] = sf.bary.y, h.bary[2] = sf.bary.z;
+            h.uv[0] = sf.uv.x, h.uv[1] = sf.uv.y;
+            h.kd[0] = sf.kd.x, h.kd[1] = sf.kd.y, h.kd[2] = sf.kd.z;
+        }
+        r[6] = T;
+        hits[i] = h;
+    }
+    /* every lane of the wave reaches the reduction: the loop above has no early return */
+    flush_counters(cnt, nPath, 0, 0, st);
+}
+
+__global__ __launch_bounds__(SRT_BLOCK) void k_generate(srt_camera cam, const float* ndc2, long long n, float* rays7)
+{
+    for (long long i = (long long)blockIdx.x * SRT_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * SRT_BLOCK) {
+        const f3 d = camera_dir(cam, ndc2[2 * i], ndc2[2 * i + 1]);
+        float* r = rays7 + 7 * i;
+        r[0] = cam.origin[0], r[1] = cam.origin[1], r[2] = cam.origin[2];
+        r[3] = d.x, r[4] = d.y, r[5] = d.z;
+        r[6] = SRT_FLT_MAX;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ host side */
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail(SRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return SRT_OK;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc(&p, bytes));
+        cap = bytes;
+        return SRT_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+#define SRT_MAX_EVENTS 64
+
+struct srt_device {
+    int gpu = 0;
+    int n_cu = 0;
+    DevCounters* counters = nullptr;
+    uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
+    DevBuf acc, hq_slot, hq_t, hq_tri, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
+    hipEvent_t ev[SRT_MAX_EVENTS];
+    int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
+    int n_ev = 0;
+    bool ev_ready = false;
+};
+
+struct srt_scene {
+    srt_device* dev = nullptr;
+    SceneDev view {};
+    uint32_t num_levels = 0;
+    std::vector<void*> allocs;
+};
+
+template <typename T>
+static int upload(srt_scene* s, const T* host, size_t count, const T** dev_out)
+{
+    *dev_out = nullptr;
+    void* p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (count)
+        HIPCHK(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = (const T*)p;
+    return SRT_OK;
+}
+
+extern "C" {
+
+const char* srt_last_error(void) { return g_err.c_str(); }
+
+int srt_device_count(int* count)
+{
+    if (!count)
+        return fail(SRT_ERR_INVALID, "srt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(SRT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SRT_OK;
+}
+
+int srt_device_create(int gpu_id, srt_device** out)
+{
+    if (!out)
+        return fail(SRT_ERR_INVALID, "srt_device_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(SRT_ERR_NO_DEVICE, "no HIP device is visible: the MI355X back end cannot run (there is no CPU fallback)");
+    if (gpu_id < 0 || gpu_id >= n)
+        return fail(SRT_ERR_INVALID, "gpu_id %d out of range [0,%d)", gpu_id, n);
+    HIPCHK(hipSetDevice(gpu_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, gpu_id));
+    srt_device* d = new srt_device();
+    d->gpu = gpu_id;
+    d->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipMalloc((void**)&d->counters, sizeof(DevCounters));
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
+    if (e == hipSuccess)
+        e = hipMemset(d->counters, 0, sizeof(DevCounters));
+    for (int i = 0; i < SRT_MAX_EVENTS && e == hipSuccess; ++i)
+        e = hipEventCreate(&d->ev[i]);
+    if (e != hipSuccess) {
+        delete d;
+        return fail(SRT_ERR_HIP, "device set-up failed: %s", hipGetErrorString(e));
+    }
+    d->ev_ready = true;
+    *out = d;
+    return SRT_OK;
+}
+
+void srt_device_destroy(srt_device* d)
+{
+    if (!d)
+        return;
+    (void)hipSetDevice(d->gpu);
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = { &d->acc, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
+        &d->out_t, &d->io_a, &d->io_b };
+    for (DevBuf* b : bufs)
+        b->release();
+    if (d->counters)
+        (void)hipFree(d->counters);
+    if (d->qcounts)
+        (void)hipFree(d->qcounts);
+    if (d->ev_ready)
+        for (int i = 0; i < SRT_MAX_EVENTS; ++i)
+            (void)hipEventDestroy(d->ev[i]);
+    delete d;
+}
+
+int srt_device_synchronize(srt_device* d, void* stream)
+{
+    if (!d)
+        return fail(SRT_ERR_INVALID, "null device");
+    HIPCHK(hipSetDevice(d->gpu));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SRT_OK;
+}
+
+int srt_device_read_counters(srt_device* d, void* stream, srt_counters* out, int reset)
+{
+    if (!d || !out)
+        return fail(SRT_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(d->gpu));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    DevCounters c;
+    HIPCHK(hipMemcpy(&c, d->counters, sizeof c, hipMemcpyDeviceToHost));
+    out->path_rays = c.path_rays;
+    out->shadow_rays = c.shadow_rays;
+    out->shaded_hits = c.shaded_hits;
+    out->inner_visits = c.inner_visits;
+    out->tri_tests = c.tri_tests;
+    out->box_tests = c.box_tests;
+    if (reset)
+        HIPCHK(hipMemset(d->counters, 0, sizeof(DevCounters)));
+    return SRT_OK;
+}
+
+int srt_device_last_kernel_ms(srt_device* d, float ms[4])
+{
+    if (!d || !ms)
+        return fail(SRT_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(d->gpu));
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
+    if (d->n_ev < 2)
+        return SRT_OK;
+    HIPCHK(hipEventSynchronize(d->ev[d->n_ev - 1]));
+    for (int i = 0; i + 1 < d->n_ev; ++i) {
+        if (d->ev_kind[i] < 0)
+            continue;
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, d->ev[i], d->ev[i + 1]));
+        ms[d->ev_kind[i]] += t;
+    }
+    return SRT_OK;
+}
+
+static int check_ref(const srt_scene_desc* d, uint32_t ref, const char* what)
+{
+    if (ref & SRT_LEAF_FLAG) {
+        uint32_t first = ref & 0x00FFFFFFu, cnt = (ref >> 24) & 0x7Fu;
+        if ((uint64_t)first + cnt > d->n_tris)
+            return fail(SRT_ERR_INVALID, "%s: leaf reference [%u,+%u) outside %u triangles", what, first, cnt, d->n_tris);
+    } else if (ref >= d->n_nodes) {
+        return fail(SRT_ERR_INVALID, "%s: node reference %u outside %u nodes", what, ref, d->n_nodes);
+    }
+    return SRT_OK;
+}
+
+int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out)
+{
+    if (!dev || !desc || !out)
+        return fail(SRT_ERR_INVALID, "srt_scene_upload: null argument");
+    *out = nullptr;
+    static_assert(sizeof(srt_node) == 64 && sizeof(srt_tri) == 96 && sizeof(srt_tri_attr) == 64, "record sizes");
+    static_assert(sizeof(srt_material) == 48 && sizeof(srt_light) == 96, "record sizes");
+    if (desc->n_tris > SRT_MAX_TRIS)
+        return fail(SRT_ERR_INVALID, "scene has %u triangles; the packed child reference addresses at most %u", desc->n_tris, SRT_MAX_TRIS);
+    if (desc->num_levels > SRT_MAX_LEVELS)
+        return fail(SRT_ERR_INVALID, "BVH has %u levels; the traversal stack supports %d", desc->num_levels, SRT_MAX_LEVELS);
+    if ((desc->n_nodes && !desc->nodes) || (desc->n_tris && (!desc->tris || !desc->attrs || !desc->scene_order))
+        || (desc->n_materials && !desc->materials) || (desc->n_lights && !desc->lights) || (desc->n_textures && (!desc->textures || !desc->texels)))
+        return fail(SRT_ERR_INVALID, "srt_scene_upload: a non-empty array is null");
+    /* Every index a kernel will follow is validated here, on the host, before anything is launched. */
+    int rc = check_ref(desc, desc->root_ref, "root");
+    for (uint32_t i = 0; i < desc->n_nodes && rc == SRT_OK; ++i) {
+        rc = check_ref(desc, desc->nodes[i].left, "left child");
+        if (rc == SRT_OK)
+            rc = check_ref(desc, desc->nodes[i].right, "right child");
+        /* breadth-first storage: children come after their parent, so a traversal cannot cycle */
+        if (rc == SRT_OK && ((!(desc->nodes[i].left & SRT_LEAF_FLAG) && desc->nodes[i].left <= i) || (!(desc->nodes[i].right & SRT_LEAF_FLAG) && desc->nodes[i].right <= i)))
+            rc = fail(SRT_ERR_INVALID, "node %u: child index does not follow its parent", i);
+    }
+    if (rc != SRT_OK)
+        return rc;
+    for (uint32_t i = 0; i < desc->n_tris; ++i) {
+        if (desc->tris[i].mesh >= desc->n_materials || desc->attrs[i].mesh >= desc->n_materials)
+            return fail(SRT_ERR_INVALID, "triangle %u: mesh index outside %u materials", i, desc->n_materials);
+        if (desc->scene_order[i] >= desc->n_tris)
+            return fail(SRT_ERR_INVALID, "scene_order[%u] outside %u triangles", i, desc->n_tris);
+    }
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        if (desc->materials[i].texture >= (int32_t)desc->n_textures)
+            return fail(SRT_ERR_INVALID, "material %u: texture index outside %u textures", i, desc->n_textures);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const srt_texture& t = desc->textures[i];
+        if (t.width == 0 || t.height == 0 || t.offset + (uint64_t)t.width * t.height > desc->n_texels)
+            return fail(SRT_ERR_INVALID, "texture %u does not fit the texel array", i);
+    }
+    for (uint32_t i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].type > 2)
+            return fail(SRT_ERR_INVALID, "light %u: unknown type %u", i, desc->lights[i].type);
+
+    HIPCHK(hipSetDevice(dev->gpu));
+    srt_scene* s = new srt_scene();
+    s->dev = dev;
+    s->num_levels = desc->num_levels;
+    SceneDev& v = s->view;
+    const srt_node* dn;
+    const srt_tri* dt;
+    const srt_tri_attr* da;
+    rc = upload(s, desc->nodes, desc->n_nodes, &dn);
+    if (rc == SRT_OK) rc = upload(s, desc->tris, desc->n_tris, &dt);
+    if (rc == SRT_OK) rc = upload(s, desc->attrs, desc->n_tris, &da);
+    if (rc == SRT_OK) rc = upload(s, desc->scene_order, desc->n_tris, &v.scene_order);
+    if (rc == SRT_OK) rc = upload(s, desc->materials, desc->n_materials, &v.materials);
+    if (rc == SRT_OK) rc = upload(s, desc->textures, desc->n_textures, &v.textures);
+    if (rc == SRT_OK) rc = upload(s, desc->texels, (size_t)desc->n_texels * 3, &v.texels);
+    if (rc == SRT_OK) rc = upload(s, desc->lights, desc->n_lights, &v.lights);
+    if (rc != SRT_OK) {
+        srt_scene_destroy(s);
+        return rc;
+    }
+    v.nodes = (const float4*)dn;
+    v.tris = (const float4*)dt;
+    v.attrs = (const float4*)da;
+    v.n_nodes = desc->n_nodes, v.n_tris = desc->n_tris, v.n_materials = desc->n_materials;
+    v.n_textures = desc->n_textures, v.n_lights = desc->n_lights;
+    v.root_ref = desc->root_ref;
+    for (int k = 0; k < 3; ++k)
+        v.root_lo[k] = desc->root_box[k], v.root_hi[k] = desc->root_box[3 + k];
+    v.n_texels = desc->n_texels;
+    *out = s;
+    return SRT_OK;
+}
+
+void srt_scene_destroy(srt_scene* s)
+{
+    if (!s)
+        return;
+    if (s->dev)
+        (void)hipSetDevice(s->dev->gpu);
+    for (void* p : s->allocs)
+        (void)hipFree(p);
+    delete s;
+}
+
+} // extern "C"
+
+/* Stack capacity: at most one pending left sibling per inner level. */
+static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + 1; }
+static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
+
+template <typename K>
+static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid)
+{
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SRT_BLOCK, lds));
+    if (per_cu < 1)
+        return fail(SRT_ERR_INVALID, "kernel does not fit a compute unit with %zu bytes of LDS", lds);
+    *grid = per_cu * d->n_cu;
+    return SRT_OK;
+}
+
+static void mark(srt_device* d, hipStream_t st, int kind, bool timing)
+{
+    if (!timing || d->n_ev >= SRT_MAX_EVENTS)
+        return;
+    (void)hipEventRecord(d->ev[d->n_ev], st);
+    d->ev_kind[d->n_ev] = kind;
+    d->n_ev += 1;
+}
+
+template <bool CULL, bool COUNT>
+static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32_t flags, hipStream_t st)
+{
+    const size_t lds = stack_bytes(sc);
+    const bool timing = (flags & SRT_RENDER_TIMING) != 0;
+    int g_primary = 0, g_secondary = 0, g_shade = 0;
+    int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, lds, &g_primary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, lds, &g_secondary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_shade<CULL, COUNT>, lds, &g_shade);
+    if (rc != SRT_OK)
+        return rc;
+    const uint32_t n = rp.n_samples;
+    const int need = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
+    if (need < g_primary) g_primary = need;
+    if (need < g_secondary) g_secondary = need;
+    if (need < g_shade) g_shade = need;
+
+    HitQ hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
+    uint32_t* hq_count = d->qcounts;
+    uint32_t* path_count = d->qcounts + 32;
+    float* acc = (float*)d->acc.p;
+    HIPCHK(hipMemsetAsync(d->qcounts, 0, 64 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
+    d->n_ev = 0;
+    mark(d, st, 0, timing);
+    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters);
+    const int last_depth = (rp.features & SRT_F_RECURSIVE) ? rp.max_depth : 0;
+    for (int depth = 0; depth <= last_depth; ++depth) {
+        const float4* cur = (const float4*)d->path[depth & 1].p;
+        float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
+        mark(d, st, 2, timing);
+        hipLaunchKernelGGL((k_shade<CULL, COUNT>), dim3(g_shade), dim3(SRT_BLOCK), lds, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt,
+            path_count + depth + 1, acc, d->counters);
+        if (depth == last_depth)
+            break;
+        mark(d, st, 1, timing);
+        hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
+            path_count + depth + 1, hq, hq_count + depth + 1, d->counters);
+    }
+    mark(d, st, 3, timing);
+    const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
+    int g_res = (int)((n_px + SRT_BLOCK - 1) / SRT_BLOCK);
+    if (g_res > d->n_cu * 8) g_res = d->n_cu * 8;
+    hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc);
+    mark(d, st, -1, timing);
+    HIPCHK(hipGetLastError());
+    return SRT_OK;
+}
+
+extern "C" {
+
+int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const srt_output* out, void* stream)
+{
+    if (!d || !sc || !p || !out || !out->rgb)
+        return fail(SRT_ERR_INVALID, "srt_render: null argument");
+    if (sc->dev != d)
+        return fail(SRT_ERR_INVALID, "srt_render: scene belongs to another device handle");
+    const srt_camera& cam = p->camera;
+    if (cam.width <= 0 || cam.height <= 0)
+        return fail(SRT_ERR_INVALID, "camera resolution %dx%d", cam.width, cam.height);
+    const int x0 = p->rect[0], y0 = p->rect[1], x1 = p->rect[2], y1 = p->rect[3];
+    if (x0 < 0 || y0 < 0 || x1 > cam.width || y1 > cam.height || x0 >= x1 || y0 >= y1)
+        return fail(SRT_ERR_INVALID, "rectangle [%d,%d)x[%d,%d) is empty or outside the %dx%d frame", x0, x1, y0, y1, cam.width, cam.height);
+    if (x0 < out->x0 || y0 < out->y0 || x1 > out->x0 + out->out_width || y1 > out->y0 + out->out_height)
+        return fail(SRT_ERR_INVALID, "rectangle does not fit the output buffer (%dx%d at %d,%d)", out->out_width, out->out_height, out->x0, out->y0);
+    int nsx = 1, nsy = 1;
+    if (p->features & SRT_F_MULTISAMPLE) {
+        nsx = p->samples_x, nsy = p->samples_y;
+        if (nsx < 1 || nsy < 1 || nsx * nsy > 4096)
+            return fail(SRT_ERR_INVALID, "sample grid %dx%d", nsx, nsy);
+    }
+    if (p->max_depth < 0 || p->max_depth > 30)
+        return fail(SRT_ERR_INVALID, "max_depth %d outside [0,30]", p->max_depth);
+    const uint64_t n64 = (uint64_t)(x1 - x0) * (uint64_t)(y1 - y0) * (uint64_t)(nsx * nsy);
+    if (n64 >= (1ull << 31))
+        return fail(SRT_ERR_INVALID, "rectangle holds %llu samples; split it below 2^31", (unsigned long long)n64);
+    if ((uint64_t)cam.width * cam.height * (uint64_t)(nsx * nsy) >= (1ull << 32))
+        return fail(SRT_ERR_INVALID, "frame holds more than 2^32 samples");
+    HIPCHK(hipSetDevice(d->gpu));
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t n = (uint32_t)n64;
+
+    int rc = d->acc.reserve((size_t)n * 12);
+    if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
+    if (rc == SRT_OK && (p->features & SRT_F_RECURSIVE)) {
+        rc = d->path[0].reserve((size_t)n * 48);
+        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * 48);
+    }
+    if (rc != SRT_OK)
+        return rc;
+
+    RenderDev rp {};
+    rp.cam = cam;
+    rp.features = p->features;
+    rp.nsx = nsx, rp.nsy = nsy, rp.S = nsx * nsy;
+    rp.max_depth = p->max_depth;
+    rp.seed = p->seed;
+    rp.x0 = x0, rp.y0 = y0, rp.tw = x1 - x0, rp.th = y1 - y0;
+    rp.n_samples = n;
+    rp.out_w = out->out_width, rp.out_h = out->out_height, rp.out_x0 = out->x0, rp.out_y0 = out->y0;
+    const size_t out_px = (size_t)out->out_width * out->out_height;
+    if (out->on_device) {
+        rp.out_rgb = out->rgb, rp.out_mesh = out->prim_mesh, rp.out_tri = out->prim_tri, rp.out_t = out->prim_t;
+    } else {
+        /* host output: render into staging buffers that mirror the caller's arrays */
+        rc = d->out_rgb.reserve(out_px * 12);
+        if (rc == SRT_OK && out->prim_mesh) rc = d->out_mesh.reserve(out_px * 4);
+        if (rc == SRT_OK && out->prim_tri) rc = d->out_tri.reserve(out_px * 4);
+        if (rc == SRT_OK && out->prim_t) rc = d->out_t.reserve(out_px * 4);
+        if (rc != SRT_OK)
+            return rc;
+        rp.out_rgb = (float*)d->out_rgb.p;
+        rp.out_mesh = out->prim_mesh ? (int32_t*)d->out_mesh.p : nullptr;
+        rp.out_tri = out->prim_tri ? (int32_t*)d->out_tri.p : nullptr;
+        rp.out_t = out->prim_t ? (float*)d->out_t.p : nullptr;
+        /* pixels outside the rectangle keep the caller's contents */
+        HIPCHK(hipMemcpyAsync(rp.out_rgb, out->rgb, out_px * 12, hipMemcpyHostToDevice, st));
+        if (rp.out_mesh) HIPCHK(hipMemcpyAsync(rp.out_mesh, out->prim_mesh, out_px * 4, hipMemcpyHostToDevice, st));
+        if (rp.out_tri) HIPCHK(hipMemcpyAsync(rp.out_tri, out->prim_tri, out_px * 4, hipMemcpyHostToDevice, st));
+        if (rp.out_t) HIPCHK(hipMemcpyAsync(rp.out_t, out->prim_t, out_px * 4, hipMemcpyHostToDevice, st));
+    }
+    const bool cull = (p->features & SRT_F_MISS_CULL) != 0;
+    const bool stats = (p->flags & SRT_RENDER_STATS) != 0;
+    if (cull && stats) rc = render_impl<true, true>(d, sc, rp, p->flags, st);
+    else if (cull) rc = render_impl<true, false>(d, sc, rp, p->flags, st);
+    else if (stats) rc = render_impl<false, true>(d, sc, rp, p->flags, st);
+    else rc = render_impl<false, false>(d, sc, rp, p->flags, st);
+    if (rc != SRT_OK)
+        return rc;
+    if (!out->on_device) {
+        HIPCHK(hipMemcpyAsync(out->rgb, rp.out_rgb, out_px * 12, hipMemcpyDeviceToHost, st));
+        if (rp.out_mesh) HIPCHK(hipMemcpyAsync(out->prim_mesh, rp.out_mesh, out_px * 4, hipMemcpyDeviceToHost, st));
+        if (rp.out_tri) HIPCHK(hipMemcpyAsync(out->prim_tri, rp.out_tri, out_px * 4, hipMemcpyDeviceToHost, st));
+        if (rp.out_t) HIPCHK(hipMemcpyAsync(out->prim_t, rp.out_t, out_px * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return SRT_OK;
+}
+
+int srt_intersect_batch(srt_device* d, srt_scene* sc, float* rays7, int64_t n, uint32_t features, srt_hit* hits, srt_counters* counters)
+{
+    if (!d || !sc || n < 0 || (n > 0 && (!rays7 || !hits)))
+        return fail(SRT_ERR_INVALID, "srt_intersect_batch: bad argument");
+    if (sc->dev != d)
+        return fail(SRT_ERR_INVALID, "srt_intersect_batch: scene belongs to another device handle");
+    if (counters)
+        memset(counters, 0, sizeof *counters);
+    if (n == 0)
+        return SRT_OK;
+    static_assert(sizeof(srt_hit) == 60, "srt_hit layout");
+    HIPCHK(hipSetDevice(d->gpu));
+    int rc = d->io_a.reserve((size_t)n * 28);
+    if (rc == SRT_OK) rc = d->io_b.reserve((size_t)n * sizeof(srt_hit));
+    if (rc != SRT_OK)
+        return rc;
+    HIPCHK(hipMemcpy(d->io_a.p, rays7, (size_t)n * 28, hipMemcpyHostToDevice));
+    DevCounters* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, sizeof(DevCounters)));
+    hipError_t e = hipMemset(tmp, 0, sizeof(DevCounters));
+    const size_t lds = stack_bytes(sc);
+    int grid = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
+    if (grid > d->n_cu * 16) grid = d->n_cu * 16;
+    if (e == hipSuccess) {
+        if (features & SRT_F_MISS_CULL)
+            hipLaunchKernelGGL(k_intersect_batch<true>, dim3(grid), dim3(SRT_BLOCK), lds, 0, sc->view, (float*)d->io_a.p, (long long)n, features,
+                (srt_hit*)d->io_b.p, tmp);
+        else
+            hipLaunchKernelGGL(k_intersect_batch<false>, dim3(grid), dim3(SRT_BLOCK), lds, 0, sc->view, (float*)d->io_a.p, (long long)n, features,
+                (srt_hit*)d->io_b.p, tmp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(rays7, d->io_a.p, (size_t)n * 28, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hits, d->io_b.p, (size_t)n * sizeof(srt_hit), hipMemcpyDeviceToHost);
+    DevCounters c {};
+    if (e == hipSuccess) e = hipMemcpy(&c, tmp, sizeof c, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess)
+        return fail(SRT_ERR_HIP, "srt_intersect_batch: %s", hipGetErrorString(e));
+    if (counters) {
+        counters->path_rays = c.path_rays, counters->shadow_rays = c.shadow_rays, counters->shaded_hits = c.shaded_hits;
+        counters->inner_visits = c.inner_visits, counters->tri_tests = c.tri_tests, counters->box_tests = c.box_tests;
+    }
+    return SRT_OK;
+}
+
+int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int64_t n, uint32_t features, int32_t max_depth, uint32_t seed, float* rgb)
+{
+    if (!d || !sc || n < 0 || (n > 0 && (!rays7 || !rgb)))
+        return fail(SRT_ERR_INVALID, "srt_final_color_batch: bad argument");
+    if (sc->dev != d)
+        return fail(SRT_ERR_INVALID, "srt_final_color_batch: scene belongs to another device handle");
+    if (n >= (1ll << 31) || max_depth < 0 || max_depth > 30)
+        return fail(SRT_ERR_INVALID, "srt_final_color_batch: n or max_depth out of range");
+    if (n == 0)
+        return SRT_OK;
+    HIPCHK(hipSetDevice(d->gpu));
+    int rc = d->io_a.reserve((size_t)n * 28);
+    if (rc == SRT_OK) rc = d->io_b.reserve((size_t)n * 12);
+    if (rc == SRT_OK) rc = d->acc.reserve((size_t)n * 12);
+    if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
+    if (rc == SRT_OK && (features & SRT_F_RECURSIVE)) {
+        rc = d->path[0].reserve((size_t)n * 48);
+        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * 48);
+    }
+    if (rc != SRT_OK)
+        return rc;
+    HIPCHK(hipMemcpy(d->io_a.p, rays7, (size_t)n * 28, hipMemcpyHostToDevice));
+    RenderDev rp {};
+    rp.cam.width = (int32_t)n, rp.cam.height = 1;
+    rp.features = features & ~SRT_F_MULTISAMPLE;
+    rp.nsx = rp.nsy = rp.S = 1;
+    rp.max_depth = max_depth;
+    rp.seed = seed;
+    rp.x0 = rp.y0 = 0, rp.tw = (int32_t)n, rp.th = 1;
+    rp.n_samples = (uint32_t)n;
+    rp.out_rgb = (float*)d->io_b.p;
+    rp.out_w = (int32_t)n, rp.out_h = 1;
+    rp.custom_rays = (const float*)d->io_a.p;
+    if (features & SRT_F_MISS_CULL)
+        rc = render_impl<true, false>(d, sc, rp, 0, 0);
+    else
+        rc = render_impl<false, false>(d, sc, rp, 0, 0);
+    if (rc != SRT_OK)
+        return rc;
+    HIPCHK(hipMemcpy(rgb, d->io_b.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_generate_rays(srt_device* d, const srt_camera* cam, const float* ndc2, int64_t n, float* rays7)
+{
+    if (!d || !cam || n < 0 || (n > 0 && (!ndc2 || !rays7)))
+        return fail(SRT_ERR_INVALID, "srt_generate_rays: bad argument");
+    if (n == 0)
+        return SRT_OK;
+    HIPCHK(hipSetDevice(d->gpu));
+    int rc = d->io_a.reserve((size_t)n * 8);
+    if (rc == SRT_OK) rc = d->io_b.reserve((size_t)n * 28);
+    if (rc != SRT_OK)
+        return rc;
+    HIPCHK(hipMemcpy(d->io_a.p, ndc2, (size_t)n * 8, hipMemcpyHostToDevice));
+    int grid = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
+    if (grid > d->n_cu * 16) grid = d->n_cu * 16;
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(SRT_BLOCK), 0, 0, *cam, (const float*)d->io_a.p, (long long)n, (float*)d->io_b.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(rays7, d->io_b.p, (size_t)n * 28, hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,606 @@
+/*
+ * srt_host.cpp -- host mirror of the reference's BVH / Screen / camera / render interface (see srt_host.h).
+ * Compiled with -ffp-contract=off: the BVH boxes, the per-triangle precomputation and the camera constants
+ * must carry exactly the bits the reference's x86-64 build produces.
+ */
+#include "srt_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <queue>
+
+namespace srt {
+
+namespace {
+
+inline vec3 operator+(vec3 a, vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+inline vec3 operator-(vec3 a, vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline vec3 operator*(vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+inline vec3 operator/(vec3 a, float s) { return { a.x / s, a.y / s, a.z / s }; }
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(vec3 x, vec3 y) { return { x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y }; }
+inline float length(vec3 v) { return std::sqrt(dot(v, v)); }
+inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+
+thread_local int t_gpu = 0;
+std::mutex g_mu;
+std::map<int, srt_device*> g_devices;
+
+[[noreturn]] void raise(const std::string& what) { throw std::runtime_error(what + ": " + srt_last_error()); }
+
+} // namespace
+
+srt_device* deviceFor(int gpu)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_devices.find(gpu);
+    if (it != g_devices.end())
+        return it->second;
+    srt_device* d = nullptr;
+    if (srt_device_create(gpu, &d) != SRT_OK)
+        raise("MI355X back end unavailable");
+    g_devices[gpu] = d;
+    return d;
+}
+
+void setDevice(int gpuId) { t_gpu = gpuId; }
+int currentDevice() { return t_gpu; }
+
+float radians(float degrees) { return degrees * 0.01745329251994329576923690768489f; }
+vec3 radians(const vec3& d) { return { radians(d.x), radians(d.y), radians(d.z) }; }
+
+uint32_t featureMask(const Features& f, bool referenceTraversal)
+{
+    uint32_t m = 0;
+    if (f.enableShading) m |= SRT_F_SHADING;
+    if (f.enableRecursive) m |= SRT_F_RECURSIVE;
+    if (f.enableHardShadow) m |= SRT_F_HARD_SHADOW;
+    if (f.enableSoftShadow) m |= SRT_F_SOFT_SHADOW;
+    if (f.enableNormalInterp) m |= SRT_F_NORMAL_INTERP;
+    if (f.enableTextureMapping) m |= SRT_F_TEXTURE;
+    if (f.enableAccelStructure) m |= SRT_F_ACCEL;
+    if (f.extra.enableMultipleRaysPerPixel) m |= SRT_F_MULTISAMPLE;
+    if (!referenceTraversal) m |= SRT_F_MISS_CULL;
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------ BVH build */
+
+/* getMedian, reference src/bounding_volume_hierarchy.cpp:37-45 */
+static vec3 getMedian(const TriangleOrNode& t, const Scene& scene)
+{
+    const Mesh& mesh = scene.meshes[t.meshIndex];
+    const uvec3& tr = mesh.triangles[t.triangleIndex];
+    const vec3 &p1 = mesh.vertices[tr.x].position, &p2 = mesh.vertices[tr.y].position, &p3 = mesh.vertices[tr.z].position;
+    return ((p1 + p2) + p3) / 3.0f;
+}
+
+/* getBox, reference :47-68 */
+static AxisAlignedBox getBox(std::vector<TriangleOrNode>::const_iterator begin, std::vector<TriangleOrNode>::const_iterator end, const Scene& scene)
+{
+    vec3 lower = { FLT_MAX, FLT_MAX, FLT_MAX };
+    vec3 upper = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    for (auto it = begin; it != end; ++it) {
+        const Mesh& mesh = scene.meshes[it->meshIndex];
+        const uvec3& tr = mesh.triangles[it->triangleIndex];
+        const vec3 &v1 = mesh.vertices[tr.x].position, &v2 = mesh.vertices[tr.y].position, &v3 = mesh.vertices[tr.z].position;
+        upper.x = std::max(std::max(upper.x, v1.x), std::max(v2.x, v3.x));
+        upper.y = std::max(std::max(upper.y, v1.y), std::max(v2.y, v3.y));
+        upper.z = std::max(std::max(upper.z, v1.z), std::max(v2.z, v3.z));
+        lower.x = std::min(std::min(lower.x, v1.x), std::min(v2.x, v3.x));
+        lower.y = std::min(std::min(lower.y, v1.y), std::min(v2.y, v3.y));
+        lower.z = std::min(std::min(lower.z, v1.z), std::min(v2.z, v3.z));
+    }
+    return { lower, upper };
+}
+
+BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene, const Features& features)
+    : m_pScene(pScene)
+{
+    std::vector<TriangleOrNode> triangles;
+    for (size_t i = 0; i < pScene->meshes.size(); ++i)
+        for (size_t j = 0; j < pScene->meshes[i].triangles.size(); ++j)
+            triangles.push_back(TriangleOrNode { i, j, 0 });
+    if (features.extra.enableBvhSahBinning)
+        sahConstructorHelper(triangles, 0, triangles.size(), 0, 0);
+    else
+        constructorHelper(triangles, 0, triangles.size(), 0, 0);
+    for (const Node& node : nodes)
+        m_numLevels = std::max(m_numLevels, node.level + 1);
+}
+
+static void sortByCentroid(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, const Scene& scene)
+{
+    /* std::sort, not std::stable_sort: equal centroids end up in libstdc++ introsort order, as in the reference (:81-85) */
+    std::sort(triangles.begin() + left, triangles.begin() + right, [&scene, whichAxis](const TriangleOrNode& a, const TriangleOrNode& b) {
+        return getMedian(a, scene)[whichAxis] < getMedian(b, scene)[whichAxis];
+    });
+}
+
+/* constructorHelper, reference :70-94: median split on the centroid, axis cycling with depth, one-triangle
+ * leaves, depth cap 17 levels, children appended before their parent */
+size_t BoundingVolumeHierarchy::constructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level)
+{
+    const auto beginIt = triangles.begin() + left, endIt = triangles.begin() + right;
+    if (right - left <= 1 || level > 16) {
+        nodes.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(beginIt, endIt, *m_pScene) });
+        m_numLeaves += 1;
+        return nodes.size() - 1;
+    }
+    sortByCentroid(triangles, left, right, whichAxis, *m_pScene);
+    const size_t median = (left + right + 1) / 2;
+    const size_t leftIndex = constructorHelper(triangles, left, median, (whichAxis + 1) % 3, level + 1);
+    const size_t rightIndex = constructorHelper(triangles, median, right, (whichAxis + 1) % 3, level + 1);
+    nodes.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, getBox(beginIt, endIt, *m_pScene) });
+    return nodes.size() - 1;
+}
+
+/* getProb, reference :96-113 */
+static float getProb(const AxisAlignedBox& inner, const AxisAlignedBox& outer)
+{
+    float ia = std::abs(inner.lower.x - inner.upper.x), ib = std::abs(inner.lower.y - inner.upper.y), ic = std::abs(inner.lower.z - inner.upper.z);
+    float oa = std::abs(outer.lower.x - outer.upper.x), ob = std::abs(outer.lower.y - outer.upper.y), oc = std::abs(outer.lower.z - outer.upper.z);
+    float areaInner = 2 * (ia * ib + ib * ic + ic * ia);
+    float areaOuter = 2 * (oa * ob + ob * oc + oc * oa);
+    if (areaOuter == 0)
+        return 0;
+    return areaInner / areaOuter;
+}
+
+/* sahConstructorHelper with calculateCostOfDivision, reference :116-178 (five candidate planes) */
+size_t BoundingVolumeHierarchy::sahConstructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level)
+{
+    const auto beginIt = triangles.begin() + left, endIt = triangles.begin() + right;
+    if (right - left <= 1 || level > 16) {
+        nodes.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(beginIt, endIt, *m_pScene) });
+        m_numLeaves += 1;
+        return nodes.size() - 1;
+    }
+    sortByCentroid(triangles, left, right, whichAxis, *m_pScene);
+    const Scene& scene = *m_pScene;
+    const size_t planesNumber = std::min(static_cast<size_t>(5), right - left - 1);
+    const float leftBoundary = getMedian(*beginIt, scene)[whichAxis];
+    const float rightBoundary = getMedian(*(endIt - 1), scene)[whichAxis];
+    const float step = (rightBoundary - leftBoundary) / (planesNumber + 1);
+    float minCost = FLT_MAX;
+    size_t median = left;
+    for (size_t i = 1; i <= planesNumber; ++i) {
+        const float boundary = leftBoundary + step * i;
+        auto middle = beginIt;
+        while (middle != endIt && getMedian(*middle, scene)[whichAxis] < boundary)
+            ++middle;
+        const AxisAlignedBox outerBox = getBox(beginIt, endIt, scene), leftBox = getBox(beginIt, middle, scene), rightBox = getBox(middle, endIt, scene);
+        const float cost = getProb(leftBox, outerBox) * (middle - beginIt) + getProb(rightBox, outerBox) * (endIt - middle);
+        if (cost < minCost) {
+            minCost = cost;
+            median = middle - triangles.begin();
+        }
+    }
+    const size_t leftIndex = sahConstructorHelper(triangles, left, median, (whichAxis + 1) % 3, level + 1);
+    const size_t rightIndex = sahConstructorHelper(triangles, median, right, (whichAxis + 1) % 3, level + 1);
+    nodes.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, getBox(beginIt, endIt, *m_pScene) });
+    return nodes.size() - 1;
+}
+
+/* ------------------------------------------------------------------------------------------ flatten */
+
+srt_scene_desc FlatScene::desc() const
+{
+    srt_scene_desc d {};
+    d.nodes = nodes.data();
+    d.n_nodes = (uint32_t)nodes.size();
+    std::memcpy(d.root_box, rootBox, sizeof rootBox);
+    d.root_ref = rootRef;
+    d.num_levels = numLevels;
+    d.tris = tris.data();
+    d.attrs = attrs.data();
+    d.n_tris = (uint32_t)tris.size();
+    d.scene_order = sceneOrder.data();
+    d.materials = materials.data();
+    d.n_materials = (uint32_t)materials.size();
+    d.textures = textures.data();
+    d.n_textures = (uint32_t)textures.size();
+    d.texels = texels.data();
+    d.n_texels = texels.size() / 3;
+    d.lights = lights.data();
+    d.n_lights = (uint32_t)lights.size();
+    return d;
+}
+
+static void put3(float* dst, vec3 v) { dst[0] = v.x, dst[1] = v.y, dst[2] = v.z; }
+static void putBox(float* dst, const AxisAlignedBox& b)
+{
+    put3(dst, b.lower);
+    put3(dst + 3, b.upper);
+}
+
+FlatScene BoundingVolumeHierarchy::flatten(int bfsLevels) const
+{
+    const Scene& scene = *m_pScene;
+    FlatScene f;
+    f.numLevels = (uint32_t)m_numLevels;
+
+    /* leaf-ordered triangle streams: leaves in the order the builder created them (left to right) */
+    std::vector<uint32_t> leafStart(nodes.size(), 0);
+    std::vector<size_t> meshBase(scene.meshes.size() + 1, 0);
+    for (size_t m = 0; m < scene.meshes.size(); ++m)
+        meshBase[m + 1] = meshBase[m] + scene.meshes[m].triangles.size();
+    f.sceneOrder.assign(meshBase.back(), 0);
+    for (size_t ni = 0; ni < nodes.size(); ++ni) {
+        const Node& n = nodes[ni];
+        if (!n.isLeaf)
+            continue;
+        if (n.triangles.size() > SRT_MAX_LEAF_TRIS)
+            throw std::runtime_error("BVH leaf holds more than 127 triangles: outside the back end's packed child reference");
+        leafStart[ni] = (uint32_t)f.tris.size();
+        for (const TriangleOrNode& t : n.triangles) {
+            const Mesh& mesh = scene.meshes[t.meshIndex];
+            const uvec3& tr = mesh.triangles[t.triangleIndex];
+            const Vertex &a = mesh.vertices[tr.x], &b = mesh.vertices[tr.y], &c = mesh.vertices[tr.z];
+            const vec3 v0 = a.position, v1 = b.position, v2 = c.position;
+            srt_tri rec {};
+            /* trianglePlane, reference src/intersect.cpp:45-59 */
+            const vec3 cr = cross(v1 - v0, v2 - v0);
+            vec3 n3 { 0, 0, 0 };
+            float D = 0;
+            if (!(length(cr) == 0.0f)) {
+                n3 = normalize(cr);
+                D = dot(v0, n3);
+            }
+            put3(rec.n, n3);
+            rec.D = D;
+            put3(rec.v0, v0), put3(rec.v1, v1), put3(rec.v2, v2);
+            rec.mesh = (uint32_t)t.meshIndex;
+            rec.tri = (uint32_t)t.triangleIndex;
+            /* second operands of the three sameSide tests, reference src/intersect.cpp:13-26 */
+            put3(rec.c0, cross(v2 - v1, v0 - v1));
+            put3(rec.c1, cross(v2 - v0, v1 - v0));
+            put3(rec.c2, cross(v1 - v0, v2 - v0));
+            srt_tri_attr at {};
+            put3(at.n0, a.normal), put3(at.n1, b.normal), put3(at.n2, c.normal);
+            at.uv0[0] = a.texCoord.x, at.uv0[1] = a.texCoord.y;
+            at.uv1[0] = b.texCoord.x, at.uv1[1] = b.texCoord.y;
+            at.uv2[0] = c.texCoord.x, at.uv2[1] = c.texCoord.y;
+            at.mesh = (uint32_t)t.meshIndex;
+            f.sceneOrder[meshBase[t.meshIndex] + t.triangleIndex] = (uint32_t)f.tris.size();
+            f.tris.push_back(rec);
+            f.attrs.push_back(at);
+        }
+    }
+    if (f.tris.size() > SRT_MAX_TRIS)
+        throw std::runtime_error("scene has more than 2^24 triangles: outside the back end's packed child reference");
+
+    auto childRef = [&](size_t ni, const std::vector<int>& newId) -> uint32_t {
+        const Node& n = nodes[ni];
+        if (n.isLeaf)
+            return SRT_LEAF_FLAG | ((uint32_t)n.triangles.size() << 24) | leafStart[ni];
+        return (uint32_t)newId[ni];
+    };
+
+    /* inner-node numbering: top bfsLevels levels breadth first, everything below depth first with the
+     * right child (visited first by the traversal) directly after its parent */
+    std::vector<int> newId(nodes.size(), -1);
+    std::vector<size_t> orderList;
+    if (!nodes.empty()) {
+        const size_t root = nodes.size() - 1;
+        putBox(f.rootBox, nodes[root].box);
+        if (!nodes[root].isLeaf) {
+            std::vector<size_t> frontier { root }, dfsRoots;
+            while (!frontier.empty()) {
+                std::vector<size_t> next;
+                for (size_t ni : frontier) {
+                    if (nodes[ni].level >= bfsLevels) {
+                        dfsRoots.push_back(ni);
+                        continue;
+                    }
+                    newId[ni] = (int)orderList.size();
+                    orderList.push_back(ni);
+                    for (const TriangleOrNode& ch : nodes[ni].triangles)
+                        if (!nodes[ch.nodeIndex].isLeaf)
+                            next.push_back(ch.nodeIndex);
+                }
+                frontier.swap(next);
+            }
+            for (size_t r : dfsRoots) {
+                std::vector<size_t> stack { r };
+                while (!stack.empty()) {
+                    const size_t ni = stack.back();
+                    stack.pop_back();
+                    newId[ni] = (int)orderList.size();
+                    orderList.push_back(ni);
+                    const size_t l = nodes[ni].triangles[0].nodeIndex, rr = nodes[ni].triangles[1].nodeIndex;
+                    if (!nodes[l].isLeaf)
+                        stack.push_back(l);
+                    if (!nodes[rr].isLeaf)
+                        stack.push_back(rr); /* popped first */
+                }
+            }
+        }
+        f.rootRef = childRef(root, newId);
+    }
+    f.nodes.resize(orderList.size());
+    for (size_t k = 0; k < orderList.size(); ++k) {
+        const Node& n = nodes[orderList[k]];
+        const size_t l = n.triangles[0].nodeIndex, r = n.triangles[1].nodeIndex;
+        srt_node& o = f.nodes[k];
+        putBox(o.lbox, nodes[l].box);
+        putBox(o.rbox, nodes[r].box);
+        o.left = childRef(l, newId);
+        o.right = childRef(r, newId);
+        o.left_level = (uint32_t)nodes[l].level;
+        o.pad = 0;
+    }
+
+    /* materials (one per mesh), distinct textures, lights */
+    std::vector<const Image*> seen;
+    for (const Mesh& mesh : scene.meshes) {
+        srt_material m {};
+        put3(m.kd, mesh.material.kd);
+        put3(m.ks, mesh.material.ks);
+        m.shininess = mesh.material.shininess;
+        m.transparency = mesh.material.transparency;
+        m.texture = -1;
+        if (const Image* im = mesh.material.kdTexture.get()) {
+            auto it = std::find(seen.begin(), seen.end(), im);
+            if (it == seen.end()) {
+                srt_texture t { (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) };
+                f.textures.push_back(t);
+                for (const vec3& p : im->pixels)
+                    f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
+                seen.push_back(im);
+                m.texture = (int32_t)seen.size() - 1;
+            } else {
+                m.texture = (int32_t)(it - seen.begin());
+            }
+        }
+        f.materials.push_back(m);
+    }
+    for (const Light& l : scene.lights) {
+        srt_light o {};
+        if (std::holds_alternative<PointLight>(l)) {
+            const PointLight& p = std::get<PointLight>(l);
+            o.type = 0;
+            put3(o.f, p.position), put3(o.f + 3, p.color);
+        } else if (std::holds_alternative<SegmentLight>(l)) {
+            const SegmentLight& s = std::get<SegmentLight>(l);
+            o.type = 1;
+            put3(o.f, s.endpoint0), put3(o.f + 3, s.endpoint1), put3(o.f + 6, s.color0), put3(o.f + 9, s.color1);
+        } else {
+            const ParallelogramLight& p = std::get<ParallelogramLight>(l);
+            o.type = 2;
+            put3(o.f, p.v0), put3(o.f + 3, p.edge01), put3(o.f + 6, p.edge02);
+            put3(o.f + 9, p.color0), put3(o.f + 12, p.color1), put3(o.f + 15, p.color2), put3(o.f + 18, p.color3);
+        }
+        f.lights.push_back(o);
+    }
+    return f;
+}
+
+/* ------------------------------------------------------------------------------------------ BvhInterface */
+
+BvhInterface::BvhInterface(Scene* pScene, const Features& features)
+    : m_impl(new BoundingVolumeHierarchy(pScene, features))
+    , m_pScene(pScene)
+    , m_gpu(currentDevice())
+{
+    srt_device* dev = deviceFor(m_gpu);
+    const FlatScene flat = m_impl->flatten(0);
+    const srt_scene_desc d = flat.desc();
+    if (srt_scene_upload(dev, &d, &m_dev) != SRT_OK) {
+        delete m_impl;
+        raise("scene upload failed");
+    }
+}
+
+BvhInterface::~BvhInterface()
+{
+    srt_scene_destroy(m_dev);
+    delete m_impl;
+}
+
+int BvhInterface::numLevels() const { return m_impl->numLevels(); }
+int BvhInterface::numLeaves() const { return m_impl->numLeaves(); }
+srt_device* BvhInterface::device() const { return deviceFor(m_gpu); }
+
+void BvhInterface::intersectBatch(float* rays7, int64_t n, const Features& features, srt_hit* hits, srt_counters* counters, bool referenceTraversal) const
+{
+    if (srt_intersect_batch(device(), m_dev, rays7, n, featureMask(features, referenceTraversal), hits, counters) != SRT_OK)
+        raise("BvhInterface::intersect");
+}
+
+bool BvhInterface::intersect(Ray& ray, HitInfo& hitInfo, const Features& features) const
+{
+    float r[7] = { ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, ray.t };
+    srt_hit h {};
+    intersectBatch(r, 1, features, &h);
+    ray.t = r[6];
+    if (!h.hit)
+        return false;
+    hitInfo.normal = { h.normal[0], h.normal[1], h.normal[2] };
+    if (features.enableNormalInterp)
+        hitInfo.barycentricCoord = { h.bary[0], h.bary[1], h.bary[2] };
+    if (features.enableTextureMapping)
+        hitInfo.texCoord = { h.uv[0], h.uv[1] };
+    hitInfo.material = m_pScene->meshes[(size_t)h.mesh].material;
+    hitInfo.material.kd = { h.kd[0], h.kd[1], h.kd[2] };
+    return true;
+}
+
+/* ------------------------------------------------------------------------------------------ Screen */
+
+Screen::Screen(const ivec2& resolution, bool)
+    : m_resolution(resolution)
+    , m_textureData(size_t(resolution.x) * size_t(resolution.y), vec3(0.0f))
+{
+}
+void Screen::clear(const vec3& color) { std::fill(m_textureData.begin(), m_textureData.end(), color); }
+void Screen::setPixel(int x, int y, const vec3& color) { m_textureData[(size_t)indexAt(x, y)] = color; }
+int Screen::indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
+
+/* writeBitmapToFile, reference src/screen.cpp:93-104: clamp to [0,1], scale by 255, truncate, opaque alpha;
+ * 32-bit BMP, rows bottom-up. */
+void Screen::writeBitmapToFile(const std::filesystem::path& filePath)
+{
+    const int w = m_resolution.x, h = m_resolution.y;
+    const uint32_t dataSize = (uint32_t)w * (uint32_t)h * 4u, headerSize = 14 + 40;
+    std::vector<uint8_t> file(headerSize + dataSize, 0);
+    auto put16 = [&](size_t at, uint16_t v) { file[at] = v & 255, file[at + 1] = v >> 8; };
+    auto put32 = [&](size_t at, uint32_t v) { for (int k = 0; k < 4; ++k) file[at + k] = (v >> (8 * k)) & 255; };
+    file[0] = 'B', file[1] = 'M';
+    put32(2, headerSize + dataSize);
+    put32(10, headerSize);
+    put32(14, 40);
+    put32(18, (uint32_t)w);
+    put32(22, (uint32_t)h);
+    put16(26, 1);
+    put16(28, 32);
+    put32(34, dataSize);
+    auto to8 = [](float c) {
+        const float cl = std::min(std::max(c, 0.0f), 1.0f);
+        return (uint8_t)(cl * 255.0f);
+    };
+    for (int row = 0; row < h; ++row) {
+        const vec3* src = m_textureData.data() + (size_t)(h - 1 - row) * w; /* BMP stores the bottom row first */
+        uint8_t* dst = file.data() + headerSize + (size_t)row * w * 4;
+        for (int x = 0; x < w; ++x) {
+            dst[4 * x + 0] = to8(src[x].z);
+            dst[4 * x + 1] = to8(src[x].y);
+            dst[4 * x + 2] = to8(src[x].x);
+            dst[4 * x + 3] = 255;
+        }
+    }
+    std::ofstream out(filePath, std::ios::binary);
+    out.write((const char*)file.data(), (std::streamsize)file.size());
+}
+
+/* ------------------------------------------------------------------------------------------ Trackball */
+
+Trackball::Trackball(float aspectRatio, float fovy, float distFromLookAt, float rotationX, float rotationY)
+    : m_fovy(fovy)
+    , m_halfScreenSpaceHeight(std::tan(m_fovy / 2.0f))
+    , m_halfScreenSpaceWidth(aspectRatio * m_halfScreenSpaceHeight)
+    , m_distanceFromLookAt(distFromLookAt)
+    , m_rotationEulerAngles(rotationX, rotationY, 0)
+{
+}
+
+void Trackball::setCamera(const vec3 lookAt, const vec3 rotations, const float dist)
+{
+    m_lookAt = lookAt;
+    m_rotationEulerAngles = rotations;
+    m_distanceFromLookAt = dist;
+}
+
+/* glm::quat(eulerAngles), glm/detail/type_quat.inl:208-217 */
+static void eulerQuat(const vec3& e, float q[4])
+{
+    const float cx = std::cos(e.x * 0.5f), cy = std::cos(e.y * 0.5f), cz = std::cos(e.z * 0.5f);
+    const float sx = std::sin(e.x * 0.5f), sy = std::sin(e.y * 0.5f), sz = std::sin(e.z * 0.5f);
+    q[0] = cx * cy * cz + sx * sy * sz;
+    q[1] = sx * cy * cz - cx * sy * sz;
+    q[2] = cx * sy * cz + sx * cy * sz;
+    q[3] = cx * cy * sz - sx * sy * cz;
+}
+/* quat * vec3, glm/detail/type_quat.inl:347-354 */
+static vec3 rotate(const float q[4], vec3 v)
+{
+    const vec3 qv { q[1], q[2], q[3] };
+    const vec3 uv = cross(qv, v), uuv = cross(qv, uv);
+    return v + ((uv * q[0]) + uuv) * 2.0f;
+}
+
+vec3 Trackball::position() const
+{
+    float q[4];
+    eulerQuat(m_rotationEulerAngles, q);
+    return m_lookAt + rotate(q, vec3(0, 0, -m_distanceFromLookAt));
+}
+
+srt_camera Trackball::deviceCamera(int width, int height) const
+{
+    srt_camera c {};
+    eulerQuat(m_rotationEulerAngles, c.quat);
+    const vec3 p = position();
+    c.origin[0] = p.x, c.origin[1] = p.y, c.origin[2] = p.z;
+    c.half_w = m_halfScreenSpaceWidth;
+    c.half_h = m_halfScreenSpaceHeight;
+    c.width = width, c.height = height;
+    return c;
+}
+
+Ray Trackball::generateRay(const vec2& pixel) const
+{
+    const srt_camera c = deviceCamera(1, 1);
+    const float ndc[2] = { pixel.x, pixel.y };
+    float r[7];
+    if (srt_generate_rays(deviceFor(currentDevice()), &c, ndc, 1, r) != SRT_OK)
+        raise("Trackball::generateRay");
+    Ray ray;
+    ray.origin = { r[0], r[1], r[2] };
+    ray.direction = { r[3], r[4], r[5] };
+    ray.t = r[6];
+    return ray;
+}
+
+/* ------------------------------------------------------------------------------------------ frame */
+
+static void rejectUnsupported(const Features& f)
+{
+    const char* what = nullptr;
+    if (f.extra.enableTransparency) what = "transparency";
+    else if (f.extra.enableEnvironmentMapping) what = "environment mapping";
+    else if (f.extra.enableMotionBlur) what = "motion blur";
+    else if (f.extra.enableDepthOfField) what = "depth of field";
+    else if (f.extra.enableBloomEffect) what = "bloom";
+    if (what)
+        throw std::runtime_error(std::string("feature not implemented by the MI355X back end: ") + what);
+}
+
+void renderRayTracing(const Scene&, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const int& numRays,
+                      const RenderOptions& opt)
+{
+    rejectUnsupported(features);
+    const ivec2 res = screen.resolution();
+    srt_render_params p {};
+    p.camera = camera.deviceCamera(res.x, res.y);
+    p.features = featureMask(features, opt.referenceTraversal);
+    p.samples_x = opt.samplesX > 0 ? opt.samplesX : numRays;
+    p.samples_y = opt.samplesY > 0 ? opt.samplesY : numRays;
+    p.max_depth = opt.maxDepth;
+    p.seed = opt.seed;
+    const bool whole = opt.rect[0] == 0 && opt.rect[1] == 0 && opt.rect[2] == 0 && opt.rect[3] == 0;
+    p.rect[0] = whole ? 0 : opt.rect[0], p.rect[1] = whole ? 0 : opt.rect[1];
+    p.rect[2] = whole ? res.x : opt.rect[2], p.rect[3] = whole ? res.y : opt.rect[3];
+    p.flags = (opt.stats ? SRT_RENDER_STATS : 0u) | (opt.timing ? SRT_RENDER_TIMING : 0u);
+    srt_output out {};
+    static_assert(sizeof(vec3) == 12, "Screen pixels are packed floats");
+    out.rgb = &screen.pixels()[0].x;
+    out.out_width = res.x, out.out_height = res.y, out.x0 = 0, out.y0 = 0;
+    out.on_device = 0;
+    if (srt_render(bvh.device(), bvh.deviceScene(), &p, &out, opt.stream) != SRT_OK)
+        raise("renderRayTracing");
+}
+
+void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const float&,
+                      const int&, const int& numRays)
+{
+    renderRayTracing(scene, camera, bvh, screen, features, numRays, RenderOptions {});
+}
+
+vec3 getFinalColor(const Scene&, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth)
+{
+    rejectUnsupported(features);
+    const float r[7] = { ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, ray.t };
+    float rgb[3] = { 0, 0, 0 };
+    /* a ray that starts at recursion depth d may bounce 5 - d more times */
+    if (srt_final_color_batch(bvh.device(), bvh.deviceScene(), r, 1, featureMask(features, false), 5 - rayDepth, 0, rgb) != SRT_OK)
+        raise("getFinalColor");
+    return { rgb[0], rgb[1], rgb[2] };
+}
+
+} // namespace srt

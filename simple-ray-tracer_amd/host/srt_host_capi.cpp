@@ -1,0 +1,326 @@
+/*
+ * srt_host_capi.cpp -- flat C entry points over the C++ host mirror, for ctypes / cgo-style callers
+ * (tests, bench.py).  Every function returns 0 or a negative status; srth_last_error() has the message.
+ */
+#include <cstring>
+#include <string>
+
+#include "srt_host.h"
+
+using namespace srt;
+
+static thread_local std::string g_err;
+
+#define SRTH_TRY(body)                 \
+    try {                              \
+        body;                          \
+        return 0;                      \
+    } catch (const std::exception& e) { \
+        g_err = e.what();              \
+        return -1;                     \
+    } catch (...) {                    \
+        g_err = "unknown error";       \
+        return -1;                     \
+    }
+
+#define SRTH_F_SAH (1u << 8) /* extra.enableBvhSahBinning; a host-side build option, not a kernel flag */
+
+static Features featuresFromMask(uint32_t m)
+{
+    Features f;
+    f.enableShading = m & SRT_F_SHADING;
+    f.enableRecursive = m & SRT_F_RECURSIVE;
+    f.enableHardShadow = m & SRT_F_HARD_SHADOW;
+    f.enableSoftShadow = m & SRT_F_SOFT_SHADOW;
+    f.enableNormalInterp = m & SRT_F_NORMAL_INTERP;
+    f.enableTextureMapping = m & SRT_F_TEXTURE;
+    f.enableAccelStructure = m & SRT_F_ACCEL;
+    f.extra.enableMultipleRaysPerPixel = m & SRT_F_MULTISAMPLE;
+    f.extra.enableBvhSahBinning = m & SRTH_F_SAH;
+    return f;
+}
+
+struct srth_scene {
+    Scene scene;
+    std::vector<std::shared_ptr<Image>> textures;
+};
+
+struct srth_bvh {
+    srth_scene* owner;
+    BvhInterface* bvh;
+};
+
+extern "C" {
+
+const char* srth_last_error(void) { return g_err.c_str(); }
+
+int srth_set_device(int gpu) { SRTH_TRY(setDevice(gpu); (void)deviceFor(gpu)) }
+
+srth_scene* srth_scene_create(void) { return new srth_scene(); }
+void srth_scene_destroy(srth_scene* s) { delete s; }
+
+int srth_scene_add_texture(srth_scene* s, int w, int h, const float* rgb)
+{
+    auto im = std::make_shared<Image>();
+    im->width = w, im->height = h;
+    im->pixels.resize((size_t)w * h);
+    std::memcpy(im->pixels.data(), rgb, (size_t)w * h * 12);
+    s->textures.push_back(im);
+    return (int)s->textures.size() - 1;
+}
+
+int srth_scene_add_mesh(srth_scene* s, const float* verts8, int nv, const uint32_t* tris3, int nt, const float* material8, int tex)
+{
+    Mesh m;
+    m.vertices.resize((size_t)nv);
+    static_assert(sizeof(Vertex) == 32, "Vertex is 8 floats");
+    std::memcpy(m.vertices.data(), verts8, (size_t)nv * 32);
+    m.triangles.resize((size_t)nt);
+    std::memcpy(m.triangles.data(), tris3, (size_t)nt * 12);
+    m.material.kd = { material8[0], material8[1], material8[2] };
+    m.material.ks = { material8[3], material8[4], material8[5] };
+    m.material.shininess = material8[6];
+    m.material.transparency = material8[7];
+    if (tex >= 0 && tex < (int)s->textures.size())
+        m.material.kdTexture = s->textures[(size_t)tex];
+    s->scene.meshes.push_back(std::move(m));
+    return (int)s->scene.meshes.size() - 1;
+}
+
+/* light22: type, then the struct's floats in declaration order */
+int srth_scene_add_light(srth_scene* s, const float* l)
+{
+    auto v = [&](int i) { return vec3(l[1 + i], l[2 + i], l[3 + i]); };
+    const int type = (int)l[0];
+    if (type == 0)
+        s->scene.lights.emplace_back(PointLight { v(0), v(3) });
+    else if (type == 1)
+        s->scene.lights.emplace_back(SegmentLight { v(0), v(3), v(6), v(9) });
+    else if (type == 2)
+        s->scene.lights.emplace_back(ParallelogramLight { v(0), v(3), v(6), v(9), v(12), v(15), v(18) });
+    else {
+        g_err = "unknown light type";
+        return -1;
+    }
+    return 0;
+}
+
+int srth_scene_load_obj(srth_scene* s, const char* path, int normalize)
+{
+    SRTH_TRY(auto sub = loadMesh(path, normalize != 0); for (auto& m : sub) s->scene.meshes.push_back(std::move(m)))
+}
+
+int srth_scene_load_prebuilt(srth_scene* s, int type, const char* dataDir) { SRTH_TRY(s->scene = loadScenePrebuilt((SceneType)type, dataDir)) }
+
+int srth_scene_num_meshes(const srth_scene* s) { return (int)s->scene.meshes.size(); }
+int srth_scene_num_lights(const srth_scene* s) { return (int)s->scene.lights.size(); }
+void srth_scene_mesh_sizes(const srth_scene* s, int m, int* nv, int* nt)
+{
+    *nv = (int)s->scene.meshes[(size_t)m].vertices.size();
+    *nt = (int)s->scene.meshes[(size_t)m].triangles.size();
+}
+/* returns 1 when the mesh has a texture; its size goes to tex_wh */
+int srth_scene_mesh_get(const srth_scene* s, int m, float* verts8, uint32_t* tris3, float* material8, int* tex_wh)
+{
+    const Mesh& mesh = s->scene.meshes[(size_t)m];
+    std::memcpy(verts8, mesh.vertices.data(), mesh.vertices.size() * 32);
+    std::memcpy(tris3, mesh.triangles.data(), mesh.triangles.size() * 12);
+    const Material& k = mesh.material;
+    const float mat[8] = { k.kd.x, k.kd.y, k.kd.z, k.ks.x, k.ks.y, k.ks.z, k.shininess, k.transparency };
+    std::memcpy(material8, mat, sizeof mat);
+    if (k.kdTexture) {
+        tex_wh[0] = k.kdTexture->width, tex_wh[1] = k.kdTexture->height;
+        return 1;
+    }
+    return 0;
+}
+void srth_scene_mesh_texture(const srth_scene* s, int m, float* rgb)
+{
+    const Image& im = *s->scene.meshes[(size_t)m].material.kdTexture;
+    std::memcpy(rgb, im.pixels.data(), im.pixels.size() * 12);
+}
+void srth_scene_light_get(const srth_scene* s, int i, float* out22)
+{
+    std::memset(out22, 0, 22 * sizeof(float));
+    const Light& l = s->scene.lights[(size_t)i];
+    if (std::holds_alternative<PointLight>(l)) {
+        out22[0] = 0;
+        std::memcpy(out22 + 1, &std::get<PointLight>(l), sizeof(PointLight));
+    } else if (std::holds_alternative<SegmentLight>(l)) {
+        out22[0] = 1;
+        std::memcpy(out22 + 1, &std::get<SegmentLight>(l), sizeof(SegmentLight));
+    } else {
+        out22[0] = 2;
+        std::memcpy(out22 + 1, &std::get<ParallelogramLight>(l), sizeof(ParallelogramLight));
+    }
+}
+
+/* ---- BVH build / flatten without touching the GPU (host logic is testable on a CPU-only machine) */
+
+struct srth_hostbvh {
+    BoundingVolumeHierarchy* bvh;
+};
+
+srth_hostbvh* srth_hostbvh_create(srth_scene* s, uint32_t features)
+{
+    try {
+        return new srth_hostbvh { new BoundingVolumeHierarchy(&s->scene, featuresFromMask(features)) };
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void srth_hostbvh_destroy(srth_hostbvh* b)
+{
+    if (b)
+        delete b->bvh;
+    delete b;
+}
+int srth_hostbvh_num_levels(const srth_hostbvh* b) { return b->bvh->numLevels(); }
+int srth_hostbvh_num_leaves(const srth_hostbvh* b) { return b->bvh->numLeaves(); }
+int srth_hostbvh_num_nodes(const srth_hostbvh* b) { return (int)b->bvh->nodeTable().size(); }
+/* Node table in the reference's post-order: per node is_leaf, level, a, b (leaf: first entry of the ordered
+ * triangle list and count; inner: left and right child) and the box as 6 floats. */
+void srth_hostbvh_dump(const srth_hostbvh* b, int32_t* meta4, float* box6)
+{
+    int first = 0;
+    const auto& nodes = b->bvh->nodeTable();
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const Node& n = nodes[i];
+        meta4[4 * i] = n.isLeaf, meta4[4 * i + 1] = n.level;
+        if (n.isLeaf) {
+            meta4[4 * i + 2] = first, meta4[4 * i + 3] = (int)n.triangles.size();
+            first += (int)n.triangles.size();
+        } else {
+            meta4[4 * i + 2] = (int)n.triangles[0].nodeIndex, meta4[4 * i + 3] = (int)n.triangles[1].nodeIndex;
+        }
+        const float bx[6] = { n.box.lower.x, n.box.lower.y, n.box.lower.z, n.box.upper.x, n.box.upper.y, n.box.upper.z };
+        std::memcpy(box6 + 6 * i, bx, sizeof bx);
+    }
+}
+int srth_hostbvh_tri_order(const srth_hostbvh* b, int32_t* mesh_tri2)
+{
+    int k = 0;
+    for (const Node& n : b->bvh->nodeTable())
+        if (n.isLeaf)
+            for (const TriangleOrNode& t : n.triangles) {
+                if (mesh_tri2)
+                    mesh_tri2[2 * k] = (int)t.meshIndex, mesh_tri2[2 * k + 1] = (int)t.triangleIndex;
+                ++k;
+            }
+    return k;
+}
+/* Flattened arrays: call with null pointers to get the sizes (n_nodes, n_tris), then with buffers. */
+int srth_hostbvh_flatten(const srth_hostbvh* b, int bfs_levels, uint32_t* sizes2, srt_node* nodes, srt_tri* tris, srt_tri_attr* attrs,
+                         uint32_t* scene_order, float* root_box6, uint32_t* root_ref)
+{
+    SRTH_TRY(const FlatScene f = b->bvh->flatten(bfs_levels); sizes2[0] = (uint32_t)f.nodes.size(); sizes2[1] = (uint32_t)f.tris.size();
+             if (nodes) std::memcpy(nodes, f.nodes.data(), f.nodes.size() * sizeof(srt_node));
+             if (tris) std::memcpy(tris, f.tris.data(), f.tris.size() * sizeof(srt_tri));
+             if (attrs) std::memcpy(attrs, f.attrs.data(), f.attrs.size() * sizeof(srt_tri_attr));
+             if (scene_order) std::memcpy(scene_order, f.sceneOrder.data(), f.sceneOrder.size() * 4);
+             if (root_box6) std::memcpy(root_box6, f.rootBox, 24); if (root_ref) * root_ref = f.rootRef)
+}
+
+/* ---- BvhInterface on the GPU */
+
+srth_bvh* srth_bvh_create(srth_scene* s, uint32_t features)
+{
+    try {
+        return new srth_bvh { s, new BvhInterface(&s->scene, featuresFromMask(features)) };
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+void srth_bvh_destroy(srth_bvh* b)
+{
+    if (b)
+        delete b->bvh;
+    delete b;
+}
+int srth_bvh_num_levels(const srth_bvh* b) { return b->bvh->numLevels(); }
+int srth_bvh_num_leaves(const srth_bvh* b) { return b->bvh->numLeaves(); }
+
+int srth_bvh_intersect(const srth_bvh* b, float* rays7, int64_t n, uint32_t features, srt_hit* hits, srt_counters* counters)
+{
+    SRTH_TRY(b->bvh->intersectBatch(rays7, n, featuresFromMask(features), hits, counters, !(features & SRT_F_MISS_CULL)))
+}
+
+int srth_final_color(const srth_bvh* b, const float* rays7, int64_t n, uint32_t features, int max_depth, uint32_t seed, float* rgb)
+{
+    if (srt_final_color_batch(b->bvh->device(), b->bvh->deviceScene(), rays7, n, features, max_depth, seed, rgb) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+/* Trackball set-up as the reference's CLI does it (src/main.cpp:474-475): fov and rotation in degrees. */
+int srth_camera_make(float fovy_deg, float dist, const float* look_at3, const float* rot_deg3, int width, int height, srt_camera* out)
+{
+    const float aspect = (width == 0 || height == 0) ? 1.0f : float(width) / float(height);
+    Trackball cam(aspect, radians(fovy_deg), dist);
+    cam.setCamera({ look_at3[0], look_at3[1], look_at3[2] }, radians(vec3(rot_deg3[0], rot_deg3[1], rot_deg3[2])), dist);
+    *out = cam.deviceCamera(width, height);
+    return 0;
+}
+
+int srth_generate_rays(const srt_camera* cam, const float* ndc2, int64_t n, float* rays7)
+{
+    try {
+        if (srt_generate_rays(deviceFor(currentDevice()), cam, ndc2, n, rays7) != SRT_OK) {
+            g_err = srt_last_error();
+            return -1;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+/* renderRayTracing for a rectangle.  Output arrays follow srt_output; `stream` is a hipStream_t. */
+int srth_render(const srth_bvh* b, const srt_render_params* params, const srt_output* out, void* stream)
+{
+    if (srt_render(b->bvh->device(), b->bvh->deviceScene(), params, out, stream) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+int srth_read_counters(const srth_bvh* b, void* stream, srt_counters* out, int reset)
+{
+    if (srt_device_read_counters(b->bvh->device(), stream, out, reset) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+int srth_last_kernel_ms(const srth_bvh* b, float* ms4)
+{
+    if (srt_device_last_kernel_ms(b->bvh->device(), ms4) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+int srth_synchronize(const srth_bvh* b, void* stream)
+{
+    if (srt_device_synchronize(b->bvh->device(), stream) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+/* Screen::writeBitmapToFile for a W*H*3 float framebuffer in Screen layout */
+int srth_write_bmp(const char* path, const float* rgb, int w, int h)
+{
+    SRTH_TRY(Screen sc({ w, h }); std::memcpy(&sc.pixels()[0].x, rgb, (size_t)w * h * 12); sc.writeBitmapToFile(path))
+}
+
+} // extern "C"
