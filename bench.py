@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Throughput of the BVH-traversal / intersection / shading path on MI355X.
+
+One step = one frame of the workload: every tile of the frame rendered by the HIP path (rays generated on the
+device, scene already resident in HBM) and, with more than one GPU, the finished tiles gathered to rank 0 over
+RCCL.  Ranks draw tiles from a shared counter (dynamic stealing); the frame is fixed, so more GPUs means strong
+scaling.  A "ray" is one BVH query (camera, reflection or shadow), counted on the device.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints one JSON line with the whole-job Mrays/s, ms per frame, the roofline record of the dominant kernel
+(device time from HIP events recorded around every launch of the timed steps) and, at N = 1, the CPU baseline
+(the CPU restatement of the reference algorithm, reference visiting rule, timed on a bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+
+def workload(name, srt):
+    standin = importlib.import_module("simple-ray-tracer_amd.standin")
+    if name == "dragon":
+        d = standin.dragon_standin()
+        d["lights"] = standin.dragon_lights()
+        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_MISS_CULL
+        return d, dict(width=3840, height=2160, features=feat, nsx=4, nsy=2, max_depth=5, cpu_block=1,
+                       label="dragon stand-in (procedural, 262144 triangles) 3840x2160, 8 spp (4x2 grid), shading + "
+                             "hard shadow (point light) + soft shadow (parallelogram light, 100 samples)")
+    if name == "teapot":
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        d = orc.load_scene_npz(os.path.join(ROOT, "tests", "golden", "scenes", "teapot.npz"))
+        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_MISS_CULL
+        return d, dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=4,
+                       label="teapot 15704 triangles 1920x1080, primary + shadow rays")
+    raise SystemExit(f"unknown workload {name}")
+
+
+def algorithmic_bytes(c):
+    """64 B per inner-node visit + 36 B per triangle test + 48 B of ray I/O per query + 64 B of attributes per
+    shaded hit."""
+    return 64 * c["inner_visits"] + 36 * c["tri_tests"] + 48 * (c["path_rays"] + c["shadow_rays"]) + 64 * c["shaded_hits"]
+
+
+def cpu_baseline(d, cfg, seconds, threads):
+    """The CPU restatement with the reference's visiting rule on seeded random pixel blocks of the same frame.
+    Worker threads draw blocks from one shared list until the time budget is used (a block that holds hits costs
+    orders of magnitude more than one that misses, so blocks are small and drawn dynamically)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import itertools
+    import threading
+    import orc
+    bvh = orc.Bvh(d, orc.F_ACCEL)
+    cam = orc.make_camera(cfg["width"], cfg["height"])
+    feat = cfg["features"] & ~orc.F_MISS_CULL
+    rng = np.random.default_rng(2026)
+    bw = cfg["cpu_block"]
+    nbx, nby = cfg["width"] // bw, cfg["height"] // bw
+    order = rng.permutation(nbx * nby)
+    it = iter(order)
+    lock = threading.Lock()
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+    totals = [0, 0]
+
+    def worker():
+        rays = blocks = 0
+        while time.perf_counter() < deadline:
+            with lock:
+                b = next(it, None)
+            if b is None:
+                break
+            x, y = int(b % nbx) * bw, int(b // nbx) * bw
+            r = bvh.render(cam, feat, nsx=cfg["nsx"], nsy=cfg["nsy"], max_depth=cfg["max_depth"], rect=(x, y, x + bw, y + bw),
+                           threads=1, primary=False)
+            c = r["counters"]
+            rays += c["path_rays"] + c["shadow_rays"]
+            blocks += 1
+        with lock:
+            totals[0] += rays
+            totals[1] += blocks
+
+    ts = [threading.Thread(target=worker) for _ in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    rays, blocks = totals
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{blocks} seeded random {bw}x{bw}-pixel blocks of the same frame ({rays} rays in {dt:.1f} s), "
+                      f"reference visiting rule (no miss culling), {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="dragon", choices=["dragon", "teapot"])
+    ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU, 480x270 otherwise)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: this benchmark measures the HIP path and has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    srt = importlib.import_module("simple-ray-tracer_amd")
+    srt.set_device(local_rank)
+    d, cfg = workload(args.workload, srt)
+    W, H = cfg["width"], cfg["height"]
+    t_build = time.perf_counter()
+    bvh = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    t_build = time.perf_counter() - t_build
+    cam = srt.make_camera(W, H)
+
+    tw, th = args.tile if args.tile else ((W, H) if world == 1 else (480, 270))
+    rects = srt.tile_rects(W, H, tw, th)
+    n_tiles = len(rects)
+    tile_px = tw * th
+    counter = None
+    if world > 1:
+        name = f"/srt_tiles_{os.environ.get('MASTER_PORT', '0')}"
+        if rank == 0:
+            counter = srt.TileCounter(name, True)
+        dist.barrier()
+        if rank != 0:
+            counter = srt.TileCounter(name, False)
+
+    stream = torch.cuda.current_stream()
+    tiles_buf = torch.zeros((n_tiles, th, tw, 3), dtype=torch.float32, device=dev)
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+    my_ids = torch.full((n_tiles,), -1, dtype=torch.int32)
+
+    def render_frame(step, flags):
+        """Draw tiles until the frame's counter runs out; at most two tiles in flight per rank so that a slow
+        tile on one GPU leaves the remaining tiles to the others."""
+        k = 0
+        events = []
+        while True:
+            t = counter.next(step) if counter else k
+            if t >= n_tiles:
+                break
+            if len(events) >= 2:
+                events[-2].synchronize()
+            p = bvh.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rects[t], flags)
+            x0, y0, x1, y1 = rects[t]
+            bvh.render_device(p, tiles_buf[k].data_ptr(), tw, th, x0, y0, stream.cuda_stream)
+            if world > 1:
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                events.append(ev)
+            my_ids[k] = t
+            k += 1
+        return k
+
+    def place(ids, tiles):
+        """Tile-local buffers (top row first) into the Screen-layout frame on rank 0."""
+        for j, t in enumerate(ids):
+            x0, y0, x1, y1 = rects[t]
+            frame[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]
+
+    def gather(k):
+        """Finished tiles to rank 0: counts and ids by all_gather (a few hundred bytes), pixels by one
+        point-to-point transfer per peer over its direct xGMI link."""
+        if world == 1:
+            if n_tiles == 1 and (tw, th) == (W, H):
+                frame.copy_(tiles_buf[0])
+            else:
+                place(my_ids[:k].tolist(), tiles_buf)
+            return
+        meta = torch.full((n_tiles + 1,), -1, dtype=torch.int32, device=dev)
+        meta[0] = k
+        meta[1:k + 1] = my_ids[:k].to(dev)
+        metas = [torch.empty_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta)
+        if rank == 0:
+            counter.reset(step_slot[0] + 1)
+            host_meta = torch.stack(metas).cpu()
+            bufs, ops = {}, []
+            for r in range(1, world):
+                kr = int(host_meta[r, 0])
+                if kr:
+                    bufs[r] = torch.empty((kr, th, tw, 3), dtype=torch.float32, device=dev)
+                    ops.append(dist.P2POp(dist.irecv, bufs[r], r))
+            reqs = dist.batch_isend_irecv(ops) if ops else []
+            place(my_ids[:k].tolist(), tiles_buf)
+            for q in reqs:
+                q.wait()
+            for r, b in bufs.items():
+                place(host_meta[r, 1:1 + len(b)].tolist(), b)
+        elif k:
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, tiles_buf[:k].contiguous(), 0)]):
+                q.wait()
+
+    step_slot = [0]
+
+    def one_step(flags):
+        k = render_frame(step_slot[0], flags)
+        gather(k)
+        step_slot[0] += 1
+        return k
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(0)
+    fence()
+    bvh.read_counters(reset=True)
+    bvh.kernel_times(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(srt.RENDER_TIMING)
+    fence()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    c = bvh.read_counters(reset=True)
+    rays = torch.tensor([c["path_rays"] + c["shadow_rays"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    rays_per_frame = float(rays.item()) / args.steps
+    times = bvh.kernel_times(reset=True)
+
+    # algorithmic work of each kernel family, from one more (untimed) frame with the counting kernels
+    bvh.read_kernel_counters(reset=True)
+    one_step(srt.RENDER_STATS)
+    fence()
+    fam = bvh.read_kernel_counters(reset=True)
+
+    if rank == 0:
+        dominant = max(times, key=lambda n: times[n]["ms"])
+        launches_timed = max(times[dominant]["launches"], 1)
+        avg_ms = times[dominant]["ms"] / launches_timed
+        launches_per_frame = launches_timed / args.steps
+        bytes_per_launch = algorithmic_bytes(fam[dominant]) / max(launches_per_frame, 1e-9)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (and ms/frame as ms_per_step), dragon 3840x2160 8spp" if args.workload == "dragon" else "Mrays/s (and ms/frame as ms_per_step)",
+            "value": rays_per_frame * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull",
+                       "rays_per_frame": rays_per_frame, "bvh_levels": bvh.num_levels, "bvh_build_upload_s": round(t_build, 3)},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches_timed": launches_timed,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(d, cfg, args.cpu_seconds, threads)
+        print(json.dumps(out), flush=True)
+    if counter:
+        if world > 1:
+            dist.barrier()
+        counter.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

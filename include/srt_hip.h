@@ -196,9 +196,13 @@ void srt_device_destroy(srt_device* dev);
 int srt_device_synchronize(srt_device* dev, void* stream);
 /* Totals since the last reset; synchronizes the stream first. */
 int srt_device_read_counters(srt_device* dev, void* stream, srt_counters* out, int reset);
-/* Milliseconds spent in each kernel family by the most recent srt_render call (HIP events recorded on
- * the call's stream): [0] primary trace, [1] secondary trace, [2] shade, [3] resolve.  Synchronizes. */
-int srt_device_last_kernel_ms(srt_device* dev, float ms[4]);
+/* The same totals split by kernel family: [0] primary trace, [1] secondary trace, [2] shade (with its inline
+ * shadow queries), [3] resolve. */
+int srt_device_read_kernel_counters(srt_device* dev, void* stream, srt_counters out[4], int reset);
+/* Device time per kernel family, summed over every srt_render call made with SRT_RENDER_TIMING since the last
+ * reset (HIP events recorded on each call's own stream around every launch), and the number of launches it
+ * covers.  Waits for the last recorded event.  At most 2048 events are kept between resets. */
+int srt_device_kernel_times(srt_device* dev, float ms[4], int32_t launches[4], int reset);
 
 /* Copies every array of the description to device memory; the host arrays stay with the caller. */
 int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);

@@ -79,7 +79,8 @@ assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 96 and ATTR_DTYPE.ite
 
 # every symbol include/srt_hip.h declares
 HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "srt_device_destroy",
-                   "srt_device_synchronize", "srt_device_read_counters", "srt_device_last_kernel_ms",
+                   "srt_device_synchronize", "srt_device_read_counters", "srt_device_read_kernel_counters",
+                   "srt_device_kernel_times",
                    "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_intersect_batch",
                    "srt_final_color_batch", "srt_generate_rays")
 
@@ -134,10 +135,17 @@ def host():
     L.srth_generate_rays.argtypes = [C.POINTER(Camera), _f32p, C.c_int64, _f32p]
     L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
-    L.srth_last_kernel_ms.argtypes = [C.c_void_p, _f32p]
+    L.srth_read_kernel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
+    L.srth_kernel_times.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int]
     L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.srth_write_bmp.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int]
     L.srth_set_device.argtypes = [C.c_int]
+    L.srth_tilecounter_open.restype = C.c_void_p
+    L.srth_tilecounter_open.argtypes = [C.c_char_p, C.c_int]
+    L.srth_tilecounter_next.restype = C.c_int64
+    L.srth_tilecounter_next.argtypes = [C.c_void_p, C.c_int]
+    L.srth_tilecounter_reset.argtypes = [C.c_void_p, C.c_int]
+    L.srth_tilecounter_close.argtypes = [C.c_void_p]
     _host = L
     return L
 
@@ -366,10 +374,19 @@ class Bvh:
         _check(host().srth_read_counters(self.h, stream, C.byref(c), int(reset)))
         return c.as_dict()
 
-    def last_kernel_ms(self):
-        ms = np.zeros(4, np.float32)
-        _check(host().srth_last_kernel_ms(self.h, _p(ms)))
-        return {"trace_primary": float(ms[0]), "trace_secondary": float(ms[1]), "shade": float(ms[2]), "resolve": float(ms[3])}
+    FAMILIES = ("trace_primary", "trace_secondary", "shade", "resolve")
+
+    def read_kernel_counters(self, stream=None, reset=False):
+        """Counters split by kernel family."""
+        c = (Counters * 4)()
+        _check(host().srth_read_kernel_counters(self.h, stream, c, int(reset)))
+        return {name: c[i].as_dict() for i, name in enumerate(self.FAMILIES)}
+
+    def kernel_times(self, reset=True):
+        """Device ms and launch count per kernel family over the render calls made with RENDER_TIMING."""
+        ms, n = np.zeros(4, np.float32), np.zeros(4, np.int32)
+        _check(host().srth_kernel_times(self.h, _p(ms), _p(n, _i32p), int(reset)))
+        return {name: {"ms": float(ms[i]), "launches": int(n[i])} for i, name in enumerate(self.FAMILIES)}
 
     def synchronize(self, stream=None):
         _check(host().srth_synchronize(self.h, stream))
@@ -393,3 +410,31 @@ def generate_rays(cam, ndc):
 def write_bmp(path, rgb):
     rgb = np.ascontiguousarray(rgb, np.float32)
     _check(host().srth_write_bmp(os.fsencode(path), _p(rgb), rgb.shape[1], rgb.shape[0]))
+
+
+class TileCounter:
+    """Frame-indexed tile counters shared by the per-GPU processes of a node (POSIX shared memory, one atomic
+    fetch-add per tile).  The creating process must open it before the others."""
+    SLOTS = 64
+
+    def __init__(self, name, create):
+        self.h = host().srth_tilecounter_open(name.encode(), int(create))
+        if not self.h:
+            raise SrtError(host().srth_last_error().decode())
+
+    def next(self, frame):
+        return int(host().srth_tilecounter_next(self.h, frame % self.SLOTS))
+
+    def reset(self, frame):
+        host().srth_tilecounter_reset(self.h, frame % self.SLOTS)
+
+    def close(self):
+        if self.h:
+            host().srth_tilecounter_close(self.h)
+            self.h = None
+
+
+def tile_rects(width, height, tile_w, tile_h):
+    """Tiles of the frame in row-major order (y up, as the render loops count); edge tiles may be smaller."""
+    return [(x, y, min(x + tile_w, width), min(y + tile_h, height))
+            for y in range(0, height, tile_h) for x in range(0, width, tile_w)]

@@ -695,12 +695,13 @@ struct DevBuf {
     }
 };
 
-#define SRT_MAX_EVENTS 64
+#define SRT_MAX_EVENTS 2048
+#define SRT_FAMILIES 4 /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve */
 
 struct srt_device {
     int gpu = 0;
     int n_cu = 0;
-    DevCounters* counters = nullptr;
+    DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
     DevBuf acc, hq_slot, hq_t, hq_tri, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
     hipEvent_t ev[SRT_MAX_EVENTS];
@@ -764,18 +765,15 @@ int srt_device_create(int gpu_id, srt_device** out)
     srt_device* d = new srt_device();
     d->gpu = gpu_id;
     d->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc((void**)&d->counters, sizeof(DevCounters));
+    hipError_t e = hipMalloc((void**)&d->counters, SRT_FAMILIES * sizeof(DevCounters));
     if (e == hipSuccess)
         e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = hipMemset(d->counters, 0, sizeof(DevCounters));
-    for (int i = 0; i < SRT_MAX_EVENTS && e == hipSuccess; ++i)
-        e = hipEventCreate(&d->ev[i]);
+        e = hipMemset(d->counters, 0, SRT_FAMILIES * sizeof(DevCounters));
     if (e != hipSuccess) {
         delete d;
         return fail(SRT_ERR_HIP, "device set-up failed: %s", hipGetErrorString(e));
     }
-    d->ev_ready = true;
     *out = d;
     return SRT_OK;
 }
@@ -809,41 +807,65 @@ int srt_device_synchronize(srt_device* d, void* stream)
     return SRT_OK;
 }
 
-int srt_device_read_counters(srt_device* d, void* stream, srt_counters* out, int reset)
+static void to_public(const DevCounters& c, srt_counters* out)
 {
-    if (!d || !out)
-        return fail(SRT_ERR_INVALID, "null argument");
-    HIPCHK(hipSetDevice(d->gpu));
-    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
-    DevCounters c;
-    HIPCHK(hipMemcpy(&c, d->counters, sizeof c, hipMemcpyDeviceToHost));
     out->path_rays = c.path_rays;
     out->shadow_rays = c.shadow_rays;
     out->shaded_hits = c.shaded_hits;
     out->inner_visits = c.inner_visits;
     out->tri_tests = c.tri_tests;
     out->box_tests = c.box_tests;
+}
+
+int srt_device_read_kernel_counters(srt_device* d, void* stream, srt_counters out[4], int reset)
+{
+    if (!d || !out)
+        return fail(SRT_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(d->gpu));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    DevCounters c[SRT_FAMILIES];
+    HIPCHK(hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost));
+    for (int k = 0; k < SRT_FAMILIES; ++k)
+        to_public(c[k], out + k);
     if (reset)
-        HIPCHK(hipMemset(d->counters, 0, sizeof(DevCounters)));
+        HIPCHK(hipMemset(d->counters, 0, sizeof c));
     return SRT_OK;
 }
 
-int srt_device_last_kernel_ms(srt_device* d, float ms[4])
+int srt_device_read_counters(srt_device* d, void* stream, srt_counters* out, int reset)
 {
-    if (!d || !ms)
+    srt_counters k[SRT_FAMILIES];
+    int rc = srt_device_read_kernel_counters(d, stream, k, reset);
+    if (rc != SRT_OK || !out)
+        return rc != SRT_OK ? rc : fail(SRT_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < SRT_FAMILIES; ++i) {
+        out->path_rays += k[i].path_rays, out->shadow_rays += k[i].shadow_rays, out->shaded_hits += k[i].shaded_hits;
+        out->inner_visits += k[i].inner_visits, out->tri_tests += k[i].tri_tests, out->box_tests += k[i].box_tests;
+    }
+    return SRT_OK;
+}
+
+int srt_device_kernel_times(srt_device* d, float ms[4], int32_t launches[4], int reset)
+{
+    if (!d || !ms || !launches)
         return fail(SRT_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(d->gpu));
-    ms[0] = ms[1] = ms[2] = ms[3] = 0.0f;
-    if (d->n_ev < 2)
-        return SRT_OK;
-    HIPCHK(hipEventSynchronize(d->ev[d->n_ev - 1]));
-    for (int i = 0; i + 1 < d->n_ev; ++i) {
-        if (d->ev_kind[i] < 0)
-            continue;
-        float t = 0;
-        HIPCHK(hipEventElapsedTime(&t, d->ev[i], d->ev[i + 1]));
-        ms[d->ev_kind[i]] += t;
+    for (int k = 0; k < SRT_FAMILIES; ++k)
+        ms[k] = 0.0f, launches[k] = 0;
+    if (d->n_ev >= 2) {
+        HIPCHK(hipEventSynchronize(d->ev[d->n_ev - 1]));
+        for (int i = 0; i + 1 < d->n_ev; ++i) {
+            if (d->ev_kind[i] < 0)
+                continue;
+            float t = 0;
+            HIPCHK(hipEventElapsedTime(&t, d->ev[i], d->ev[i + 1]));
+            ms[d->ev_kind[i]] += t;
+            launches[d->ev_kind[i]] += 1;
+        }
     }
+    if (reset)
+        d->n_ev = 0;
     return SRT_OK;
 }
 
@@ -964,9 +986,20 @@ static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid)
     return SRT_OK;
 }
 
+/* Records one event of the timing ring; the interval that starts at it belongs to kernel family `kind`
+ * (-1 closes a call's last interval).  When the ring is full, further launches are simply not timed. */
 static void mark(srt_device* d, hipStream_t st, int kind, bool timing)
 {
-    if (!timing || d->n_ev >= SRT_MAX_EVENTS)
+    if (!timing)
+        return;
+    if (!d->ev_ready) {
+        for (int i = 0; i < SRT_MAX_EVENTS; ++i)
+            if (hipEventCreate(&d->ev[i]) != hipSuccess)
+                return;
+        d->ev_ready = true;
+    }
+    /* keep room for a closing event so that an interval never runs into the next call */
+    if (d->n_ev >= SRT_MAX_EVENTS - (kind >= 0 ? 1 : 0))
         return;
     (void)hipEventRecord(d->ev[d->n_ev], st);
     d->ev_kind[d->n_ev] = kind;
@@ -996,21 +1029,20 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     float* acc = (float*)d->acc.p;
     HIPCHK(hipMemsetAsync(d->qcounts, 0, 64 * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
-    d->n_ev = 0;
     mark(d, st, 0, timing);
-    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters);
+    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0);
     const int last_depth = (rp.features & SRT_F_RECURSIVE) ? rp.max_depth : 0;
     for (int depth = 0; depth <= last_depth; ++depth) {
         const float4* cur = (const float4*)d->path[depth & 1].p;
         float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
         mark(d, st, 2, timing);
         hipLaunchKernelGGL((k_shade<CULL, COUNT>), dim3(g_shade), dim3(SRT_BLOCK), lds, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt,
-            path_count + depth + 1, acc, d->counters);
+            path_count + depth + 1, acc, d->counters + 2);
         if (depth == last_depth)
             break;
         mark(d, st, 1, timing);
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
-            path_count + depth + 1, hq, hq_count + depth + 1, d->counters);
+            path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1);
     }
     mark(d, st, 3, timing);
     const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;

@@ -299,9 +299,18 @@ int srth_read_counters(const srth_bvh* b, void* stream, srt_counters* out, int r
     return 0;
 }
 
-int srth_last_kernel_ms(const srth_bvh* b, float* ms4)
+int srth_read_kernel_counters(const srth_bvh* b, void* stream, srt_counters* out4, int reset)
 {
-    if (srt_device_last_kernel_ms(b->bvh->device(), ms4) != SRT_OK) {
+    if (srt_device_read_kernel_counters(b->bvh->device(), stream, out4, reset) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
+int srth_kernel_times(const srth_bvh* b, float* ms4, int32_t* launches4, int reset)
+{
+    if (srt_device_kernel_times(b->bvh->device(), ms4, launches4, reset) != SRT_OK) {
         g_err = srt_last_error();
         return -1;
     }
@@ -321,6 +330,66 @@ int srth_synchronize(const srth_bvh* b, void* stream)
 int srth_write_bmp(const char* path, const float* rgb, int w, int h)
 {
     SRTH_TRY(Screen sc({ w, h }); std::memcpy(&sc.pixels()[0].x, rgb, (size_t)w * h * 12); sc.writeBitmapToFile(path))
+}
+
+} // extern "C"
+
+/* ---- tile stealing between the per-GPU processes of one node: an array of 64-bit counters in POSIX shared
+ * memory.  Every process draws the next tile index of the current frame with one fetch-add; there is no other
+ * coordination on the data path.  (The reference distributes rows over OpenMP threads with schedule(guided),
+ * src/render.cpp:184-187; this is the same idea across processes.) */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+#include <atomic>
+
+#define SRTH_TILE_SLOTS 64
+
+struct srth_tilecounter {
+    std::atomic<int64_t>* slots;
+    std::string name;
+    bool owner;
+};
+
+extern "C" {
+
+srth_tilecounter* srth_tilecounter_open(const char* name, int create)
+{
+    const size_t bytes = SRTH_TILE_SLOTS * sizeof(std::atomic<int64_t>);
+    static_assert(sizeof(std::atomic<int64_t>) == 8 && std::atomic<int64_t>::is_always_lock_free, "plain 8-byte atomics");
+    int fd = shm_open(name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) {
+        g_err = std::string("shm_open failed for ") + name;
+        return nullptr;
+    }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) {
+        close(fd);
+        g_err = "ftruncate failed on the tile counter";
+        return nullptr;
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        g_err = "mmap failed on the tile counter";
+        return nullptr;
+    }
+    auto* t = new srth_tilecounter { (std::atomic<int64_t>*)p, name, create != 0 };
+    if (create)
+        for (int i = 0; i < SRTH_TILE_SLOTS; ++i)
+            t->slots[i].store(0);
+    return t;
+}
+int64_t srth_tilecounter_next(srth_tilecounter* t, int slot) { return t->slots[slot % SRTH_TILE_SLOTS].fetch_add(1); }
+void srth_tilecounter_reset(srth_tilecounter* t, int slot) { t->slots[slot % SRTH_TILE_SLOTS].store(0); }
+void srth_tilecounter_close(srth_tilecounter* t)
+{
+    if (!t)
+        return;
+    munmap((void*)t->slots, SRTH_TILE_SLOTS * sizeof(std::atomic<int64_t>));
+    if (t->owner)
+        shm_unlink(t->name.c_str());
+    delete t;
 }
 
 } // extern "C"
