@@ -279,7 +279,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches_timed": launches_timed,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times}},
+                         "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times},
+                         "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

@@ -157,6 +157,8 @@ typedef struct srt_counters {
     uint64_t inner_visits; /* counted only with SRT_RENDER_STATS / in srt_intersect_batch */
     uint64_t tri_tests;
     uint64_t box_tests;
+    uint64_t wave_inner_steps; /* inner-node loop trips summed over waves (64 lanes each): lane efficiency = */
+    uint64_t wave_leaf_steps;  /* inner_visits / (64 * wave_inner_steps); likewise for leaves */
 } srt_counters;
 
 typedef struct srt_render_params {
@@ -196,13 +198,14 @@ void srt_device_destroy(srt_device* dev);
 int srt_device_synchronize(srt_device* dev, void* stream);
 /* Totals since the last reset; synchronizes the stream first. */
 int srt_device_read_counters(srt_device* dev, void* stream, srt_counters* out, int reset);
-/* The same totals split by kernel family: [0] primary trace, [1] secondary trace, [2] shade (with its inline
- * shadow queries), [3] resolve. */
-int srt_device_read_kernel_counters(srt_device* dev, void* stream, srt_counters out[4], int reset);
+/* The same totals split by kernel family: [0] primary trace, [1] secondary trace, [2] shade, [3] resolve,
+ * [4] shadow trace. */
+#define SRT_KERNEL_FAMILIES 5
+int srt_device_read_kernel_counters(srt_device* dev, void* stream, srt_counters out[SRT_KERNEL_FAMILIES], int reset);
 /* Device time per kernel family, summed over every srt_render call made with SRT_RENDER_TIMING since the last
  * reset (HIP events recorded on each call's own stream around every launch), and the number of launches it
  * covers.  Waits for the last recorded event.  At most 2048 events are kept between resets. */
-int srt_device_kernel_times(srt_device* dev, float ms[4], int32_t launches[4], int reset);
+int srt_device_kernel_times(srt_device* dev, float ms[SRT_KERNEL_FAMILIES], int32_t launches[SRT_KERNEL_FAMILIES], int reset);
 
 /* Copies every array of the description to device memory; the host arrays stay with the caller. */
 int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);

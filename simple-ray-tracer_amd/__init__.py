@@ -61,7 +61,8 @@ class Output(C.Structure):
 
 
 class Counters(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("path_rays", "shadow_rays", "shaded_hits", "inner_visits", "tri_tests", "box_tests")]
+    _fields_ = [(n, C.c_uint64) for n in ("path_rays", "shadow_rays", "shaded_hits", "inner_visits", "tri_tests", "box_tests", "wave_inner_steps",
+                                           "wave_leaf_steps")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -374,17 +375,17 @@ class Bvh:
         _check(host().srth_read_counters(self.h, stream, C.byref(c), int(reset)))
         return c.as_dict()
 
-    FAMILIES = ("trace_primary", "trace_secondary", "shade", "resolve")
+    FAMILIES = ("trace_primary", "trace_secondary", "shade", "resolve", "trace_shadow")
 
     def read_kernel_counters(self, stream=None, reset=False):
         """Counters split by kernel family."""
-        c = (Counters * 4)()
+        c = (Counters * 5)()
         _check(host().srth_read_kernel_counters(self.h, stream, c, int(reset)))
         return {name: c[i].as_dict() for i, name in enumerate(self.FAMILIES)}
 
     def kernel_times(self, reset=True):
         """Device ms and launch count per kernel family over the render calls made with RENDER_TIMING."""
-        ms, n = np.zeros(4, np.float32), np.zeros(4, np.int32)
+        ms, n = np.zeros(5, np.float32), np.zeros(5, np.int32)
         _check(host().srth_kernel_times(self.h, _p(ms), _p(n, _i32p), int(reset)))
         return {name: {"ms": float(ms[i]), "launches": int(n[i])} for i, name in enumerate(self.FAMILIES)}
 

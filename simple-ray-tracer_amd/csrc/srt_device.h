@@ -78,6 +78,74 @@ SRT_DI bool slab_test(const float lo[3], const float hi[3], f3 o, f3 d, float T,
     return true;
 }
 
+/* ---- division by a ray-constant denominator.
+ * The slab test divides twelve differences by the same three direction components at every node.  hipcc expands
+ * a correctly rounded x / d into: scale operands if their exponents are extreme (v_div_scale), r0 = v_rcp(d),
+ * e = fma(-d, r0, 1), r1 = fma(e, r0, r0), q = x * r1, s = fma(-d, q, x), q = fma(s, r1, q), s = fma(-d, q, x),
+ * q = fma(s, r1, q) (v_div_fmas), then a fix-up for zero / infinite / NaN operands (v_div_fixup).  When no scaling
+ * and no fix-up can trigger, the quotient is exactly the five operations after r1, and r1 depends on d alone, so
+ * it is computed once per ray.  "No scaling, no fix-up" is guaranteed by keeping operands in these ranges:
+ *   direction component   2^-20 <= |d| <= 2^20
+ *   origin / box coordinate   0, or 2^-40 <= |c| < 2^20      (so x = box - origin is 0 or |x| >= 2^-63)
+ * which puts every quotient and every intermediate in the normal range.  A zero numerator gives a zero of
+ * possibly the other sign than x / d; slab values only feed comparisons, for which the sign of zero is irrelevant.
+ * Rays or scenes outside the ranges take the plain-division path. */
+struct RayRcp {
+    float x, y, z;
+};
+SRT_DI float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+SRT_DI float div_by(float x, float d, float r1)
+{
+    float q = x * r1;
+    float s = __builtin_fmaf(-d, q, x);
+    q = __builtin_fmaf(s, r1, q);
+    s = __builtin_fmaf(-d, q, x);
+    return __builtin_fmaf(s, r1, q);
+}
+SRT_DI bool dir_in_fast_range(float d)
+{
+    const uint32_t e = (__float_as_uint(d) >> 23) & 0xFFu;
+    return e >= 107u && e <= 147u; /* 2^-20 <= |d| < 2^21; 2^20 itself has e == 147 */
+}
+SRT_DI bool coord_in_fast_range(float c)
+{
+    const uint32_t b = __float_as_uint(c) & 0x7FFFFFFFu;
+    const uint32_t e = b >> 23;
+    return b == 0u || (e >= 87u && e < 147u);
+}
+
+/* slab_test with the divisions done by div_by; identical results for operands in the fast ranges. */
+SRT_DI bool slab_test_fast(const float lo[3], const float hi[3], f3 o, f3 d, RayRcp r, float T, float& val, bool& inside)
+{
+    float txmin = div_by(lo[0] - o.x, d.x, r.x);
+    float tymin = div_by(lo[1] - o.y, d.y, r.y);
+    float tzmin = div_by(lo[2] - o.z, d.z, r.z);
+    float txmax = div_by(hi[0] - o.x, d.x, r.x);
+    float tymax = div_by(hi[1] - o.y, d.y, r.y);
+    float tzmax = div_by(hi[2] - o.z, d.z, r.z);
+    float tinx = min_std(txmin, txmax), toutx = max_std(txmin, txmax);
+    float tiny = min_std(tymin, tymax), touty = max_std(tymin, tymax);
+    float tinz = min_std(tzmin, tzmax), toutz = max_std(tzmin, tzmax);
+    float tin = max_std(tinx, max_std(tiny, tinz));
+    float tout = min_std(toutx, min_std(touty, toutz));
+    inside = false;
+    if (tin > tout || tout < 0 || tin > T) {
+        val = T;
+        return false;
+    }
+    val = tin;
+    if (tin <= 0) {
+        val = tout;
+        inside = true;
+    }
+    return true;
+}
+
 /* Ray/triangle test, reference src/intersect.cpp:13-77, on a precomputed srt_tri record (six float4).
  * On acceptance T becomes the new distance. */
 SRT_DI bool tri_test(const float4* __restrict__ rec, f3 o, f3 d, float& T)

@@ -5,11 +5,13 @@
  *
  *   trace_primary   one lane per pixel sample: camera ray (Trackball::generateRay) + BVH query; lanes that
  *                   hit are compacted (wave ballot + one atomic per wave) into the hit queue
- *   shade           one lane per queued hit: hit attributes, light loop with the shadow-ray BVH queries
- *                   traced inline by the same traversal routine, accumulation into the sample's slot,
+ *   trace_shadow    one lane per (queued hit, light sample): the shadow-ray BVH query of that sample, by the same
+ *                   traversal routine; one visibility bit per pair
+ *   shade           one lane per queued hit: hit attributes, light loop (Phong term of every sample times its
+ *                   visibility bit, summed in the reference's order) into the sample's accumulator slot,
  *                   reflection ray compacted into the next path queue
  *   trace_secondary one lane per queued path ray: BVH query, hits compacted into the hit queue
- *   ... shade / trace_secondary repeat up to max_depth times ...
+ *   ... trace_shadow / shade / trace_secondary repeat up to max_depth times ...
  *   resolve         one lane per pixel: sum of the pixel's samples in the reference's loop order, division,
  *                   store at Screen::setPixel's position
  *
@@ -55,15 +57,17 @@ struct SceneDev {
     uint32_t n_nodes, n_tris, n_materials, n_textures, n_lights;
     uint32_t root_ref;
     float root_lo[3], root_hi[3];
+    uint32_t fast_boxes; /* every box coordinate is 0 or 2^-40 <= |c| < 2^20: div_by applies (srt_device.h) */
     uint64_t n_texels;
 };
 
 struct DevCounters {
-    unsigned long long path_rays, shadow_rays, shaded_hits, inner_visits, tri_tests, box_tests;
+    unsigned long long path_rays, shadow_rays, shaded_hits, inner_visits, tri_tests, box_tests, wave_inner_steps, wave_leaf_steps;
 };
 
 struct Stats {
     uint32_t inner, tri, box;
+    uint32_t wave_inner, wave_leaf; /* loop trips of the wave, tallied by its first active lane */
 };
 
 /* A queued path ray is three float4: (o.xyz, d.x) (d.y, d.z, thr.x, thr.y) (thr.z, sample, -, -). */
@@ -104,6 +108,7 @@ SRT_DI void flush_counters(DevCounters* c, uint32_t path, uint32_t shadow, uint3
 {
     uint32_t a = wave_sum(path), b = wave_sum(shadow), s = wave_sum(shaded);
     uint32_t i = wave_sum(st.inner), t = wave_sum(st.tri), x = wave_sum(st.box);
+    uint32_t wi = wave_sum(st.wave_inner), wl = wave_sum(st.wave_leaf);
     if ((threadIdx.x & 63) == 0) {
         if (a) atomicAdd(&c->path_rays, (unsigned long long)a);
         if (b) atomicAdd(&c->shadow_rays, (unsigned long long)b);
@@ -111,6 +116,8 @@ SRT_DI void flush_counters(DevCounters* c, uint32_t path, uint32_t shadow, uint3
         if (i) atomicAdd(&c->inner_visits, (unsigned long long)i);
         if (t) atomicAdd(&c->tri_tests, (unsigned long long)t);
         if (x) atomicAdd(&c->box_tests, (unsigned long long)x);
+        if (wi) atomicAdd(&c->wave_inner_steps, (unsigned long long)wi);
+        if (wl) atomicAdd(&c->wave_leaf_steps, (unsigned long long)wl);
     }
 }
 
@@ -132,89 +139,122 @@ SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& 
 }
 
 /* BVH query.  stk points at this lane's column of the block's LDS stack (entry k at stk[k * SRT_BLOCK]).
- * Returns whether anything was accepted; T is the final Ray::t, hitTri the last accepted triangle. */
-template <bool CULL, bool COUNT>
-SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
+ * Returns whether anything was accepted; T is the final Ray::t, hitTri the last accepted triangle.
+ *
+ * Loop shape.  A lane stands either on an inner node (box-pair test, ~120 vector instructions) or on a leaf
+ * (triangle tests).  Each trip the wave votes (ballot) and runs only the kind of step more of its lanes are
+ * waiting for; the others keep their node for a later trip.  A wave therefore never pays for both kinds of work
+ * in one trip, and at least half of its live lanes advance.  Which lane advances when does not change any
+ * lane's own visiting order.  FAST selects div_by for the slab divisions.  ANYHIT is for shadow queries: their
+ * caller only asks "accepted something and final t < 0.99"; t never grows, so the first accepted hit below
+ * 0.99 settles the answer and the walk stops there. */
+template <bool CULL, bool COUNT, bool FAST, bool ANYHIT>
+SRT_DI bool traverse_loop(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     float C = SRT_FLT_MAX;
+    RayRcp rr = { 0, 0, 0 };
+    if (FAST)
+        rr.x = refined_rcp(d.x), rr.y = refined_rcp(d.y), rr.z = refined_rcp(d.z);
     float val;
     bool inside;
-    bool pass = slab_test(sc.root_lo, sc.root_hi, o, d, T, val, inside);
+    bool pass = FAST ? slab_test_fast(sc.root_lo, sc.root_hi, o, d, rr, T, val, inside) : slab_test(sc.root_lo, sc.root_hi, o, d, T, val, inside);
     if (COUNT)
         st.box += 1;
-    if (!(val < C && (pass || !CULL)))
-        return false;
+    bool alive = val < C && (pass || !CULL);
     uint32_t cur = sc.root_ref;
     int sp = 0;
-    for (;;) {
-        bool need_pop;
-        if (cur & SRT_LEAF_FLAG) {
-            const uint32_t first = cur & 0x00FFFFFFu;
-            const uint32_t cnt = (cur >> 24) & 0x7Fu;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                if (COUNT)
-                    st.tri += 1;
-                if (tri_test(sc.tris + 6ull * (first + k), o, d, T)) {
-                    C = min_std(C, T);
-                    hitTri = first + k;
-                }
-            }
-            need_pop = true;
-        } else {
-            if (COUNT) {
-                st.inner += 1;
-                st.box += 2;
-            }
-            const float4* nd = sc.nodes + 4ull * cur;
-            const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
-            const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
-            const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
-            const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
-            float lval, rval;
-            bool lin, rin;
-            const bool lpass = slab_test(llo, lhi, o, d, T, lval, lin);
-            const bool rpass = slab_test(rlo, rhi, o, d, T, rval, rin);
-            const bool pushL = lval < C && (lpass || !CULL);
-            const bool pushR = rval < C && (rpass || !CULL);
-            need_pop = false;
-            if (pushL && pushR) {
-                /* pending left sibling; v as described at the top of the file */
-                const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
-                stk[sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
-                ++sp;
-                cur = right;
-            } else if (pushR) {
-                cur = right;
-            } else if (pushL) {
-                cur = left;
-            } else {
-                need_pop = true;
+    /* next pending left sibling that the reference would not skip at pop; false when the stack is empty */
+    auto pop = [&]() -> bool {
+        while (sp > 0) {
+            --sp;
+            const uint2 en = stk[sp * SRT_BLOCK];
+            if (!(__uint_as_float(en.y) > C)) {
+                cur = en.x;
+                return true;
             }
         }
-        if (need_pop) {
-            bool got = false;
-            while (sp > 0) {
-                --sp;
-                const uint2 en = stk[sp * SRT_BLOCK];
-                if (!(__uint_as_float(en.y) > C)) {
-                    cur = en.x;
-                    got = true;
-                    break;
+        return false;
+    };
+    for (;;) {
+        const bool atLeaf = alive && (cur & SRT_LEAF_FLAG);
+        const bool atInner = alive && !(cur & SRT_LEAF_FLAG);
+        const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
+        if ((mInner | mLeaf) == 0)
+            break;
+        if (__popcll(mInner) >= __popcll(mLeaf)) {
+            if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mInner) - 1)
+                st.wave_inner += 1;
+            if (atInner) {
+                if (COUNT) {
+                    st.inner += 1;
+                    st.box += 2;
+                }
+                const float4* nd = sc.nodes + 4ull * cur;
+                const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+                const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+                const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
+                const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
+                float lval, rval;
+                bool lin, rin;
+                const bool lpass = FAST ? slab_test_fast(llo, lhi, o, d, rr, T, lval, lin) : slab_test(llo, lhi, o, d, T, lval, lin);
+                const bool rpass = FAST ? slab_test_fast(rlo, rhi, o, d, rr, T, rval, rin) : slab_test(rlo, rhi, o, d, T, rval, rin);
+                const bool pushL = lval < C && (lpass || !CULL);
+                const bool pushR = rval < C && (rpass || !CULL);
+                if (pushL && pushR) {
+                    /* pending left sibling; v as described at the top of the file */
+                    const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
+                    stk[sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
+                    ++sp;
+                    cur = right;
+                } else if (pushR) {
+                    cur = right;
+                } else if (pushL) {
+                    cur = left;
+                } else {
+                    alive = pop();
                 }
             }
-            if (!got)
-                break;
+        } else {
+            if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mLeaf) - 1)
+                st.wave_leaf += 1;
+            if (atLeaf) {
+                const uint32_t first = cur & 0x00FFFFFFu;
+                const uint32_t cnt = (cur >> 24) & 0x7Fu;
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    if (COUNT)
+                        st.tri += 1;
+                    if (tri_test(sc.tris + 6ull * (first + k), o, d, T)) {
+                        C = min_std(C, T);
+                        hitTri = first + k;
+                    }
+                }
+                if (ANYHIT && T < 0.99f && C != SRT_FLT_MAX)
+                    alive = false;
+                else
+                    alive = pop();
+            }
         }
     }
     return C != SRT_FLT_MAX;
 }
 
-template <bool CULL, bool COUNT>
+template <bool CULL, bool COUNT, bool ANYHIT>
+SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
+{
+    /* one decision per wave: every lane's operands in the ranges div_by is exact for, or plain division for all */
+    const bool ok = sc.fast_boxes && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z) && coord_in_fast_range(o.x)
+        && coord_in_fast_range(o.y) && coord_in_fast_range(o.z);
+    if (__all(ok))
+        return traverse_loop<CULL, COUNT, true, ANYHIT>(sc, o, d, T, hitTri, stk, st);
+    return traverse_loop<CULL, COUNT, false, ANYHIT>(sc, o, d, T, hitTri, stk, st);
+}
+
+template <bool CULL, bool COUNT, bool ANYHIT = false>
 SRT_DI bool bvh_query(const SceneDev& sc, uint32_t features, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     hitTri = 0xFFFFFFFFu;
     if (features & SRT_F_ACCEL)
-        return traverse<CULL, COUNT>(sc, o, d, T, hitTri, stk, st);
+        return traverse<CULL, COUNT, ANYHIT>(sc, o, d, T, hitTri, stk, st);
     return traverse_linear<COUNT>(sc, o, d, T, hitTri, st);
 }
 
@@ -283,77 +323,103 @@ SRT_DI void surface_at(const SceneDev& sc, uint32_t features, f3 o, f3 d, float 
     }
 }
 
-/* testVisibilityLightSample, reference src/light.cpp:43-74 */
-template <bool CULL, bool COUNT>
-SRT_DI float visibility(const SceneDev& sc, uint32_t features, f3 samplePos, f3 ip, uint2* stk, Stats& st, uint32_t& nShadow)
+/* ------------------------------------------------------------------------------------------ lights
+ * computeLightContribution and its samplers (reference src/light.cpp:14-39,109-166) are split over two
+ * kernels: trace_shadow answers testVisibilityLightSample (src/light.cpp:43-74) for every (hit, light sample)
+ * pair, one lane each, and leaves one bit per pair; shade then walks the lights and samples in the
+ * reference's order, computes the Phong term of each sample and multiplies it by that bit.  Both kernels
+ * derive a sample's position from the same function below, so they agree bit for bit. */
+
+/* Shadow queries the reference issues for one light at one hit. */
+SRT_DI uint32_t shadow_samples(uint32_t type, uint32_t features)
 {
-    if (!(features & (SRT_F_HARD_SHADOW | SRT_F_SOFT_SHADOW)))
-        return 1.0f;
+    if (type == 0)
+        return (features & SRT_F_HARD_SHADOW) ? 1u : 0u;
+    return (features & SRT_F_SOFT_SHADOW) ? 100u : 0u;
+}
+
+/* Position and colour of sample s of a light: the light itself for a point light, sampleSegmentLight with
+ * t = (s + r) / 100, or sampleParallelogramLight with (i + r1) / 10, (j + r2) / 10, s = 10 i + j.  The reference
+ * draws r from libc rand(); here it comes from the counter-based generator keyed by (seed, path, depth, light,
+ * sample). */
+SRT_DI void light_sample(const srt_light* L, uint32_t seed, uint32_t path, uint32_t depth, uint32_t li, uint32_t s, f3& pos, f3& col)
+{
+    const uint32_t type = L->type;
+    if (type == 0) {
+        pos = mk3(L->f[0], L->f[1], L->f[2]);
+        col = mk3(L->f[3], L->f[4], L->f[5]);
+    } else if (type == 1) {
+        const f3 e0 = mk3(L->f[0], L->f[1], L->f[2]), e1 = mk3(L->f[3], L->f[4], L->f[5]);
+        const f3 c0 = mk3(L->f[6], L->f[7], L->f[8]), c1 = mk3(L->f[9], L->f[10], L->f[11]);
+        const float r = rand01(seed, path, depth, li, s, 0);
+        const float a = ((float)s + r) / 100.0f;
+        pos = mk3(e0.x * a + e1.x * (1 - a), e0.y * a + e1.y * (1 - a), e0.z * a + e1.z * (1 - a));
+        col = mk3(c0.x * a + c1.x * (1 - a), c0.y * a + c1.y * (1 - a), c0.z * a + c1.z * (1 - a));
+    } else {
+        const f3 p0 = mk3(L->f[0], L->f[1], L->f[2]), e01 = mk3(L->f[3], L->f[4], L->f[5]);
+        const f3 e02 = mk3(L->f[6], L->f[7], L->f[8]);
+        const f3 c0 = mk3(L->f[9], L->f[10], L->f[11]), c1 = mk3(L->f[12], L->f[13], L->f[14]);
+        const f3 c2 = mk3(L->f[15], L->f[16], L->f[17]), c3 = mk3(L->f[18], L->f[19], L->f[20]);
+        const uint32_t i = s / 10u, j = s - i * 10u;
+        const float r1 = rand01(seed, path, depth, li, s, 0);
+        const float r2 = rand01(seed, path, depth, li, s, 1);
+        const float x = ((float)i + r1) / 10.0f;
+        const float y = ((float)j + r2) / 10.0f;
+        pos = (p0 + (x * e01)) + (y * e02);
+        col = ((((c0 * (1 - x)) * (1 - y)) + ((c1 * x) * (1 - y))) + ((c2 * y) * (1 - x))) + ((c3 * x) * y);
+    }
+}
+
+/* testVisibilityLightSample, reference src/light.cpp:43-74 (the shadow flags are known to be set here) */
+template <bool CULL, bool COUNT>
+SRT_DI bool light_visible(const SceneDev& sc, uint32_t features, f3 samplePos, f3 ip, uint2* stk, Stats& st, uint32_t& nShadow)
+{
     if (ip.x == samplePos.x && ip.y == samplePos.y && ip.z == samplePos.z)
-        return 1.0f;
+        return true;
     f3 dir = samplePos - ip;
     f3 org = ip + normalize3(dir) * 0.001f;
     float T = 1.0f;
     uint32_t tri;
     nShadow += 1;
     /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
-    if (bvh_query<CULL, COUNT>(sc, features, org, dir, T, tri, stk, st) && T < 0.99f)
-        return 0.0f;
-    return 1.0f;
+    if (bvh_query<CULL, COUNT, true>(sc, features, org, dir, T, tri, stk, st) && T < 0.99f)
+        return false;
+    return true;
 }
 
-/* computeLightContribution with its samplers, reference src/light.cpp:14-39,109-166 */
-template <bool CULL, bool COUNT>
-SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t seed, uint32_t path, uint32_t depth, f3 o,
-                             f3 d, float T, const Surface& s, uint2* stk, Stats& st, uint32_t& nShadow)
+/* The shade kernel's half: lights and samples in the reference's order; vis holds this hit's visibility bits
+ * starting at bit index bit0. */
+SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t seed, uint32_t path, uint32_t depth, f3 o, f3 d, float T,
+                             const Surface& s, const unsigned long long* __restrict__ vis, unsigned long long bit0)
 {
     if (!(features & SRT_F_SHADING))
         return s.kd;
     f3 res = mk3(0, 0, 0);
-    const f3 ip = o + d * T;
+    unsigned long long bit = bit0;
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const srt_light* L = sc.lights + li;
         const uint32_t type = L->type;
+        const uint32_t n = shadow_samples(type, features);
         if (type == 0) {
-            const f3 pos = mk3(L->f[0], L->f[1], L->f[2]), col = mk3(L->f[3], L->f[4], L->f[5]);
+            f3 pos, col;
+            light_sample(L, seed, path, depth, li, 0, pos, col);
             const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
-            if (features & SRT_F_HARD_SHADOW)
-                res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
-            else
+            if (n) {
+                const float v = ((vis[bit >> 6] >> (bit & 63)) & 1ull) ? 1.0f : 0.0f;
+                res = res + sh * v;
+                bit += 1;
+            } else {
                 res = res + sh;
-        } else if (type == 1) {
-            if (!(features & SRT_F_SOFT_SHADOW))
-                continue;
-            const f3 e0 = mk3(L->f[0], L->f[1], L->f[2]), e1 = mk3(L->f[3], L->f[4], L->f[5]);
-            const f3 c0 = mk3(L->f[6], L->f[7], L->f[8]), c1 = mk3(L->f[9], L->f[10], L->f[11]);
-            const int N = 100;
-            for (int t = 0; t < N; ++t) {
-                const float r = rand01(seed, path, depth, li, (uint32_t)t, 0);
-                const float a = ((float)t + r) / (float)N;
-                const f3 pos = mk3(e0.x * a + e1.x * (1 - a), e0.y * a + e1.y * (1 - a), e0.z * a + e1.z * (1 - a));
-                const f3 col = mk3(c0.x * a + c1.x * (1 - a), c0.y * a + c1.y * (1 - a), c0.z * a + c1.z * (1 - a));
-                const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / (float)N;
-                res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
             }
         } else {
-            if (!(features & SRT_F_SOFT_SHADOW))
-                continue;
-            const f3 p0 = mk3(L->f[0], L->f[1], L->f[2]), e01 = mk3(L->f[3], L->f[4], L->f[5]);
-            const f3 e02 = mk3(L->f[6], L->f[7], L->f[8]);
-            const f3 c0 = mk3(L->f[9], L->f[10], L->f[11]), c1 = mk3(L->f[12], L->f[13], L->f[14]);
-            const f3 c2 = mk3(L->f[15], L->f[16], L->f[17]), c3 = mk3(L->f[18], L->f[19], L->f[20]);
-            const int N = 10;
-            for (int i = 0; i < N; ++i) {
-                for (int j = 0; j < N; ++j) {
-                    const float r1 = rand01(seed, path, depth, li, (uint32_t)(i * N + j), 0);
-                    const float r2 = rand01(seed, path, depth, li, (uint32_t)(i * N + j), 1);
-                    const float x = ((float)i + r1) / (float)N;
-                    const float y = ((float)j + r2) / (float)N;
-                    const f3 pos = (p0 + (x * e01)) + (y * e02);
-                    const f3 col = ((((c0 * (1 - x)) * (1 - y)) + ((c1 * x) * (1 - y))) + ((c2 * y) * (1 - x))) + ((c3 * x) * y);
-                    const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / (float)(N * N);
-                    res = res + sh * visibility<CULL, COUNT>(sc, features, pos, ip, stk, st, nShadow);
-                }
+            /* segment: 100 samples, each weighted 1/100; parallelogram: 10 x 10 samples, each weighted 1/100 */
+            for (uint32_t k = 0; k < n; ++k) {
+                f3 pos, col;
+                light_sample(L, seed, path, depth, li, k, pos, col);
+                const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
+                const float v = ((vis[bit >> 6] >> (bit & 63)) & 1ull) ? 1.0f : 0.0f;
+                res = res + sh * v;
+                bit += 1;
             }
         }
     }
@@ -433,7 +499,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, Render
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
-    Stats st = { 0, 0, 0 };
+    Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nPath = 0;
     const uint32_t stride = gridDim.x * SRT_BLOCK;
     for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < rp.n_samples; base += stride) {
@@ -476,7 +542,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
-    Stats st = { 0, 0, 0 };
+    Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nPath = 0;
     const uint32_t n = *n_paths;
     const uint32_t stride = gridDim.x * SRT_BLOCK;
@@ -501,18 +567,86 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
     flush_counters(cnt, nPath, 0, 0, st);
 }
 
-/* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).  The
- * reference's Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is accumulated front to back as
- * Lo_0 + (ks_0) * Lo_1 + (ks_0 * ks_1) * Lo_2 + ...; identical for paths of at most one bounce. */
+/* Path ray and hit point data of queued hit h, as the shade kernel sees them. */
+SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4* cur_paths, uint32_t h, f3& o, f3& d, f3& thr, float& T,
+                    uint32_t& tri, uint32_t& sample, uint32_t& path)
+{
+    const uint32_t slot = hq.slot[h];
+    T = hq.t[h];
+    tri = hq.tri[h];
+    int px, py, sub;
+    if (depth == 0) {
+        sample = slot;
+        float T0;
+        primary_ray(rp, sample, o, d, T0, px, py, sub);
+        thr = mk3(1, 1, 1);
+    } else {
+        const float4 a = cur_paths[3ull * slot], b = cur_paths[3ull * slot + 1], c = cur_paths[3ull * slot + 2];
+        o = mk3(a.x, a.y, a.z);
+        d = mk3(a.w, b.x, b.y);
+        thr = mk3(b.z, b.w, c.x);
+        sample = __float_as_uint(c.y);
+        if (rp.custom_rays)
+            px = (int)sample, py = 0, sub = 0;
+        else
+            sample_decode(rp, sample, px, py, sub);
+    }
+    /* sampler key: frame-global sample number, so a frame does not depend on how it is cut into rectangles */
+    path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
+}
+
+/* Shadow queries of one recursion depth: item i = hit (i / shadows_per_hit), shadow sample (i % shadows_per_hit)
+ * in the order the reference's light loop issues them.  The 64 lanes of a wave hold consecutive samples of
+ * (mostly) one hit: same origin, neighbouring targets on the light, so they walk the tree together.  The wave
+ * writes its 64 answers as one word (bit = visible). */
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
-                                                       const float4* cur_paths, float4* next_paths, uint32_t* next_count, float* acc,
-                                                       DevCounters* cnt)
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
+                                                              const float4* cur_paths, unsigned long long* vis, uint32_t shadows_per_hit,
+                                                              DevCounters* cnt)
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
-    Stats st = { 0, 0, 0 };
-    uint32_t nShadow = 0, nShaded = 0;
+    Stats st = { 0, 0, 0, 0, 0 };
+    uint32_t nShadow = 0;
+    const unsigned long long n = (unsigned long long)(*hq_count) * shadows_per_hit;
+    const unsigned long long stride = (unsigned long long)gridDim.x * SRT_BLOCK;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
+        const unsigned long long i = base + (threadIdx.x & 63u);
+        bool visible = false;
+        if (i < n) {
+            const uint32_t h = (uint32_t)(i / shadows_per_hit);
+            uint32_t k = (uint32_t)(i - (unsigned long long)h * shadows_per_hit);
+            uint32_t li = 0;
+            for (; li < sc.n_lights; ++li) {
+                const uint32_t c = shadow_samples(sc.lights[li].type, rp.features);
+                if (k < c)
+                    break;
+                k -= c;
+            }
+            f3 o, d, thr;
+            float T;
+            uint32_t tri, sample, path;
+            hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
+            f3 pos, col;
+            light_sample(sc.lights + li, rp.seed, path, (uint32_t)depth, li, k, pos, col);
+            visible = light_visible<CULL, COUNT>(sc, rp.features, pos, o + d * T, stk, st, nShadow);
+        }
+        const unsigned long long word = __ballot(visible);
+        if ((threadIdx.x & 63u) == 0)
+            vis[base >> 6] = word;
+    }
+    flush_counters(cnt, 0, nShadow, 0, st);
+}
+
+/* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).  The
+ * reference's Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is accumulated front to back as
+ * Lo_0 + (ks_0) * Lo_1 + (ks_0 * ks_1) * Lo_2 + ...; identical for paths of at most one bounce. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count, const float4* cur_paths,
+                                                       float4* next_paths, uint32_t* next_count, float* acc, const unsigned long long* vis,
+                                                       uint32_t shadows_per_hit, DevCounters* cnt)
+{
+    Stats st = { 0, 0, 0, 0, 0 };
+    uint32_t nShaded = 0;
     const uint32_t n = *hq_count;
     const uint32_t stride = gridDim.x * SRT_BLOCK;
     for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
@@ -521,33 +655,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), nthr = mk3(0, 0, 0);
         uint32_t sample = 0;
         if (h < n) {
-            const uint32_t slot = hq.slot[h];
-            const float T = hq.t[h];
-            const uint32_t tri = hq.tri[h];
             f3 o, d, thr;
-            int px, py, sub;
-            if (depth == 0) {
-                sample = slot;
-                float T0;
-                primary_ray(rp, sample, o, d, T0, px, py, sub);
-                thr = mk3(1, 1, 1);
-            } else {
-                const float4 a = cur_paths[3ull * slot], b = cur_paths[3ull * slot + 1], c = cur_paths[3ull * slot + 2];
-                o = mk3(a.x, a.y, a.z);
-                d = mk3(a.w, b.x, b.y);
-                thr = mk3(b.z, b.w, c.x);
-                sample = __float_as_uint(c.y);
-                if (rp.custom_rays)
-                    px = (int)sample, py = 0, sub = 0;
-                else
-                    sample_decode(rp, sample, px, py, sub);
-            }
+            float T;
+            uint32_t tri, path;
+            hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
             Surface sf;
             surface_at(sc, rp.features, o, d, T, tri, sf);
             nShaded += 1;
-            /* sampler key: frame-global sample number, so a frame does not depend on how it is cut into rectangles */
-            const uint32_t path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
-            const f3 Lo = light_contribution<CULL, COUNT>(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, stk, st, nShadow);
+            const f3 Lo = light_contribution(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, vis, (unsigned long long)h * shadows_per_hit);
             float* a3 = acc + 3ull * sample;
             if (depth == 0) {
                 a3[0] = Lo.x, a3[1] = Lo.y, a3[2] = Lo.z;
@@ -574,7 +689,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             next_paths[3ull * q + 2] = make_float4(nthr.z, __uint_as_float(sample), 0.0f, 0.0f);
         }
     }
-    flush_counters(cnt, 0, nShadow, nShaded, st);
+    flush_counters(cnt, 0, 0, nShaded, st);
 }
 
 /* Pixel value from its samples (reference src/render.cpp:213-217) stored at Screen::setPixel's position. */
@@ -604,7 +719,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_intersect_batch(SceneDev sc, floa
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
-    Stats st = { 0, 0, 0 };
+    Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nPath = 0;
     const long long stride = (long long)gridDim.x * SRT_BLOCK;
     for (long long i = (long long)blockIdx.x * SRT_BLOCK + threadIdx.x; i < n; i += stride) {
@@ -696,14 +811,14 @@ struct DevBuf {
 };
 
 #define SRT_MAX_EVENTS 2048
-#define SRT_FAMILIES 4 /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve */
+#define SRT_FAMILIES SRT_KERNEL_FAMILIES /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve, 4 shadow trace */
 
 struct srt_device {
     int gpu = 0;
     int n_cu = 0;
     DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
-    DevBuf acc, hq_slot, hq_t, hq_tri, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
+    DevBuf acc, hq_slot, hq_t, hq_tri, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
     hipEvent_t ev[SRT_MAX_EVENTS];
     int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
     int n_ev = 0;
@@ -714,6 +829,7 @@ struct srt_scene {
     srt_device* dev = nullptr;
     SceneDev view {};
     uint32_t num_levels = 0;
+    std::vector<uint32_t> light_types; /* host copy: sizes the shadow-query stage */
     std::vector<void*> allocs;
 };
 
@@ -784,7 +900,7 @@ void srt_device_destroy(srt_device* d)
         return;
     (void)hipSetDevice(d->gpu);
     (void)hipDeviceSynchronize();
-    DevBuf* bufs[] = { &d->acc, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
+    DevBuf* bufs[] = { &d->acc, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
         &d->out_t, &d->io_a, &d->io_b };
     for (DevBuf* b : bufs)
         b->release();
@@ -815,9 +931,11 @@ static void to_public(const DevCounters& c, srt_counters* out)
     out->inner_visits = c.inner_visits;
     out->tri_tests = c.tri_tests;
     out->box_tests = c.box_tests;
+    out->wave_inner_steps = c.wave_inner_steps;
+    out->wave_leaf_steps = c.wave_leaf_steps;
 }
 
-int srt_device_read_kernel_counters(srt_device* d, void* stream, srt_counters out[4], int reset)
+int srt_device_read_kernel_counters(srt_device* d, void* stream, srt_counters out[SRT_KERNEL_FAMILIES], int reset)
 {
     if (!d || !out)
         return fail(SRT_ERR_INVALID, "null argument");
@@ -842,11 +960,12 @@ int srt_device_read_counters(srt_device* d, void* stream, srt_counters* out, int
     for (int i = 0; i < SRT_FAMILIES; ++i) {
         out->path_rays += k[i].path_rays, out->shadow_rays += k[i].shadow_rays, out->shaded_hits += k[i].shaded_hits;
         out->inner_visits += k[i].inner_visits, out->tri_tests += k[i].tri_tests, out->box_tests += k[i].box_tests;
+        out->wave_inner_steps += k[i].wave_inner_steps, out->wave_leaf_steps += k[i].wave_leaf_steps;
     }
     return SRT_OK;
 }
 
-int srt_device_kernel_times(srt_device* d, float ms[4], int32_t launches[4], int reset)
+int srt_device_kernel_times(srt_device* d, float ms[SRT_KERNEL_FAMILIES], int32_t launches[SRT_KERNEL_FAMILIES], int reset)
 {
     if (!d || !ms || !launches)
         return fail(SRT_ERR_INVALID, "null argument");
@@ -929,6 +1048,8 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     srt_scene* s = new srt_scene();
     s->dev = dev;
     s->num_levels = desc->num_levels;
+    for (uint32_t i = 0; i < desc->n_lights; ++i)
+        s->light_types.push_back(desc->lights[i].type);
     SceneDev& v = s->view;
     const srt_node* dn;
     const srt_tri* dt;
@@ -954,6 +1075,20 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     for (int k = 0; k < 3; ++k)
         v.root_lo[k] = desc->root_box[k], v.root_hi[k] = desc->root_box[3 + k];
     v.n_texels = desc->n_texels;
+    auto coord_ok = [](float c) {
+        uint32_t b;
+        memcpy(&b, &c, 4);
+        b &= 0x7FFFFFFFu;
+        const uint32_t e = b >> 23;
+        return b == 0u || (e >= 87u && e < 147u);
+    };
+    bool fast = true;
+    for (int k = 0; k < 6; ++k)
+        fast = fast && coord_ok(desc->root_box[k]);
+    for (uint32_t i = 0; i < desc->n_nodes && fast; ++i)
+        for (int k = 0; k < 6; ++k)
+            fast = fast && coord_ok(desc->nodes[i].lbox[k]) && coord_ok(desc->nodes[i].rbox[k]);
+    v.fast_boxes = fast ? 1u : 0u;
     *out = s;
     return SRT_OK;
 }
@@ -1006,27 +1141,48 @@ static void mark(srt_device* d, hipStream_t st, int kind, bool timing)
     d->n_ev += 1;
 }
 
+/* Shadow queries per hit: the same count the kernels derive from the light list (shadow_samples). */
+static uint32_t shadows_per_hit(const srt_scene* sc, uint32_t features)
+{
+    uint32_t n = 0;
+    if (!(features & SRT_F_SHADING))
+        return 0;
+    for (uint32_t t : sc->light_types)
+        n += t == 0 ? ((features & SRT_F_HARD_SHADOW) ? 1u : 0u) : ((features & SRT_F_SOFT_SHADOW) ? 100u : 0u);
+    return n;
+}
+
 template <bool CULL, bool COUNT>
 static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32_t flags, hipStream_t st)
 {
     const size_t lds = stack_bytes(sc);
     const bool timing = (flags & SRT_RENDER_TIMING) != 0;
-    int g_primary = 0, g_secondary = 0, g_shade = 0;
-    int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, lds, &g_primary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, lds, &g_secondary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_shade<CULL, COUNT>, lds, &g_shade);
+    const uint32_t n = rp.n_samples;
+    const uint32_t sph = shadows_per_hit(sc, rp.features);
+    /* one visibility bit per (hit, shadow sample), written as whole 64-bit words */
+    const unsigned long long vis_words = ((unsigned long long)n * sph + 63ull) / 64ull + 1ull;
+    int rc = d->vis.reserve((size_t)vis_words * 8);
     if (rc != SRT_OK)
         return rc;
-    const uint32_t n = rp.n_samples;
+    int g_primary = 0, g_secondary = 0, g_shadow = 0, g_shade = 0;
+    rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, lds, &g_primary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, lds, &g_secondary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, lds, &g_shadow);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g_shade);
+    if (rc != SRT_OK)
+        return rc;
     const int need = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
     if (need < g_primary) g_primary = need;
     if (need < g_secondary) g_secondary = need;
     if (need < g_shade) g_shade = need;
+    const unsigned long long need_shadow = ((unsigned long long)n * sph + SRT_BLOCK - 1) / SRT_BLOCK;
+    if (need_shadow < (unsigned long long)g_shadow) g_shadow = (int)need_shadow;
 
     HitQ hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
     uint32_t* hq_count = d->qcounts;
     uint32_t* path_count = d->qcounts + 32;
     float* acc = (float*)d->acc.p;
+    unsigned long long* vis = (unsigned long long*)d->vis.p;
     HIPCHK(hipMemsetAsync(d->qcounts, 0, 64 * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
     mark(d, st, 0, timing);
@@ -1035,9 +1191,14 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     for (int depth = 0; depth <= last_depth; ++depth) {
         const float4* cur = (const float4*)d->path[depth & 1].p;
         float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
+        if (sph) {
+            mark(d, st, 4, timing);
+            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_BLOCK), lds, st, sc->view, rp, depth, hq, hq_count + depth, cur,
+                vis, sph, d->counters + 4);
+        }
         mark(d, st, 2, timing);
-        hipLaunchKernelGGL((k_shade<CULL, COUNT>), dim3(g_shade), dim3(SRT_BLOCK), lds, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt,
-            path_count + depth + 1, acc, d->counters + 2);
+        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
+            acc, (const unsigned long long*)vis, sph, d->counters + 2);
         if (depth == last_depth)
             break;
         mark(d, st, 1, timing);
@@ -1188,6 +1349,7 @@ int srt_intersect_batch(srt_device* d, srt_scene* sc, float* rays7, int64_t n, u
     if (counters) {
         counters->path_rays = c.path_rays, counters->shadow_rays = c.shadow_rays, counters->shaded_hits = c.shaded_hits;
         counters->inner_visits = c.inner_visits, counters->tri_tests = c.tri_tests, counters->box_tests = c.box_tests;
+        counters->wave_inner_steps = c.wave_inner_steps, counters->wave_leaf_steps = c.wave_leaf_steps;
     }
     return SRT_OK;
 }
