@@ -87,6 +87,7 @@ SRT_DI bool slab_test(const float lo[3], const float hi[3], f3 o, f3 d, float T,
  * it is computed once per ray.  "No scaling, no fix-up" is guaranteed by keeping operands in these ranges:
  *   direction component   2^-20 <= |d| <= 2^20
  *   origin / box coordinate   0, or 2^-40 <= |c| < 2^20      (so x = box - origin is 0 or |x| >= 2^-63)
+ *   box                       lower <= upper on every axis   (false only for the empty scene's root)
  * which puts every quotient and every intermediate in the normal range.  A zero numerator gives a zero of
  * possibly the other sign than x / d; slab values only feed comparisons, for which the sign of zero is irrelevant.
  * Rays or scenes outside the ranges take the plain-division path. */
@@ -119,20 +120,22 @@ SRT_DI bool coord_in_fast_range(float c)
     return b == 0u || (e >= 87u && e < 147u);
 }
 
-/* slab_test with the divisions done by div_by; identical results for operands in the fast ranges. */
+/* slab_test for operands in the fast ranges and a box with lower <= upper on every axis; same val / inside /
+ * result.  Correctly rounded subtraction and division are monotone, so with d > 0 the lower bound gives the
+ * smaller quotient and std::min(t_min, t_max) IS t_min (t_max for d < 0): the per-axis min / max of the reference
+ * become a selection of the near and far bound by the sign of d, made before the division.  No operand can be
+ * NaN here, so the three-way max / min of the reference equal v_max3_f32 / v_min3_f32. */
 SRT_DI bool slab_test_fast(const float lo[3], const float hi[3], f3 o, f3 d, RayRcp r, float T, float& val, bool& inside)
 {
-    float txmin = div_by(lo[0] - o.x, d.x, r.x);
-    float tymin = div_by(lo[1] - o.y, d.y, r.y);
-    float tzmin = div_by(lo[2] - o.z, d.z, r.z);
-    float txmax = div_by(hi[0] - o.x, d.x, r.x);
-    float tymax = div_by(hi[1] - o.y, d.y, r.y);
-    float tzmax = div_by(hi[2] - o.z, d.z, r.z);
-    float tinx = min_std(txmin, txmax), toutx = max_std(txmin, txmax);
-    float tiny = min_std(tymin, tymax), touty = max_std(tymin, tymax);
-    float tinz = min_std(tzmin, tzmax), toutz = max_std(tzmin, tzmax);
-    float tin = max_std(tinx, max_std(tiny, tinz));
-    float tout = min_std(toutx, min_std(touty, toutz));
+    const bool nx = d.x < 0, ny = d.y < 0, nz = d.z < 0;
+    const float tinx = div_by((nx ? hi[0] : lo[0]) - o.x, d.x, r.x);
+    const float tiny = div_by((ny ? hi[1] : lo[1]) - o.y, d.y, r.y);
+    const float tinz = div_by((nz ? hi[2] : lo[2]) - o.z, d.z, r.z);
+    const float toutx = div_by((nx ? lo[0] : hi[0]) - o.x, d.x, r.x);
+    const float touty = div_by((ny ? lo[1] : hi[1]) - o.y, d.y, r.y);
+    const float toutz = div_by((nz ? lo[2] : hi[2]) - o.z, d.z, r.z);
+    const float tin = __builtin_fmaxf(tinx, __builtin_fmaxf(tiny, tinz));
+    const float tout = __builtin_fminf(toutx, __builtin_fminf(touty, toutz));
     inside = false;
     if (tin > tout || tout < 0 || tin > T) {
         val = T;

@@ -57,7 +57,7 @@ struct SceneDev {
     uint32_t n_nodes, n_tris, n_materials, n_textures, n_lights;
     uint32_t root_ref;
     float root_lo[3], root_hi[3];
-    uint32_t fast_boxes; /* every box coordinate is 0 or 2^-40 <= |c| < 2^20: div_by applies (srt_device.h) */
+    uint32_t fast_boxes; /* every box has lower <= upper and coordinates 0 or 2^-40 <= |c| < 2^20: slab_test_fast applies */
     uint64_t n_texels;
 };
 
@@ -1082,12 +1082,15 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         const uint32_t e = b >> 23;
         return b == 0u || (e >= 87u && e < 147u);
     };
-    bool fast = true;
-    for (int k = 0; k < 6; ++k)
-        fast = fast && coord_ok(desc->root_box[k]);
-    for (uint32_t i = 0; i < desc->n_nodes && fast; ++i)
+    auto box_ok = [&](const float* b) {
+        bool ok = true;
         for (int k = 0; k < 6; ++k)
-            fast = fast && coord_ok(desc->nodes[i].lbox[k]) && coord_ok(desc->nodes[i].rbox[k]);
+            ok = ok && coord_ok(b[k]);
+        return ok && b[0] <= b[3] && b[1] <= b[4] && b[2] <= b[5];
+    };
+    bool fast = box_ok(desc->root_box);
+    for (uint32_t i = 0; i < desc->n_nodes && fast; ++i)
+        fast = box_ok(desc->nodes[i].lbox) && box_ok(desc->nodes[i].rbox);
     v.fast_boxes = fast ? 1u : 0u;
     *out = s;
     return SRT_OK;
