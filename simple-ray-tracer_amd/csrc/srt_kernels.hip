@@ -148,103 +148,151 @@ SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& 
  * lane's own visiting order.  FAST selects div_by for the slab divisions.  ANYHIT is for shadow queries: their
  * caller only asks "accepted something and final t < 0.99"; t never grows, so the first accepted hit below
  * 0.99 settles the answer and the walk stops there. */
+/* One BVH query in flight on a lane. */
+struct Walk {
+    f3 o, d;
+    RayRcp rr;
+    float T, C;
+    uint32_t cur, hitTri;
+    int sp;
+    bool alive;
+};
+
+/* Starts a query: the root's push test (reference :344-346). */
+template <bool CULL, bool COUNT, bool FAST>
+SRT_DI void walk_begin(const SceneDev& sc, Walk& w, f3 o, f3 d, float T0, Stats& st)
+{
+    w.o = o, w.d = d, w.T = T0, w.C = SRT_FLT_MAX;
+    w.rr.x = w.rr.y = w.rr.z = 0.0f;
+    if (FAST)
+        w.rr.x = refined_rcp(d.x), w.rr.y = refined_rcp(d.y), w.rr.z = refined_rcp(d.z);
+    float val;
+    bool inside;
+    const bool pass = FAST ? slab_test_fast(sc.root_lo, sc.root_hi, o, d, w.rr, T0, val, inside) : slab_test(sc.root_lo, sc.root_hi, o, d, T0, val, inside);
+    if (COUNT)
+        st.box += 1;
+    w.alive = val < w.C && (pass || !CULL);
+    w.cur = sc.root_ref;
+    w.hitTri = 0xFFFFFFFFu;
+    w.sp = 0;
+}
+
+/* Next pending left sibling that the reference would not skip at pop; false when the stack is empty. */
+SRT_DI bool walk_pop(Walk& w, const uint2* stk)
+{
+    while (w.sp > 0) {
+        --w.sp;
+        const uint2 en = stk[w.sp * SRT_BLOCK];
+        if (!(__uint_as_float(en.y) > w.C)) {
+            w.cur = en.x;
+            return true;
+        }
+    }
+    return false;
+}
+
+/* Visit of the inner node the lane stands on: both children's push tests (reference :370-385). */
+template <bool CULL, bool COUNT, bool FAST>
+SRT_DI void walk_inner(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
+{
+    if (COUNT) {
+        st.inner += 1;
+        st.box += 2;
+    }
+    const float4* nd = sc.nodes + 4ull * w.cur;
+    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+    const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
+    const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
+    float lval, rval;
+    bool lin, rin;
+    const bool lpass = FAST ? slab_test_fast(llo, lhi, w.o, w.d, w.rr, w.T, lval, lin) : slab_test(llo, lhi, w.o, w.d, w.T, lval, lin);
+    const bool rpass = FAST ? slab_test_fast(rlo, rhi, w.o, w.d, w.rr, w.T, rval, rin) : slab_test(rlo, rhi, w.o, w.d, w.T, rval, rin);
+    const bool pushL = lval < w.C && (lpass || !CULL);
+    const bool pushR = rval < w.C && (rpass || !CULL);
+    if (pushL && pushR) {
+        /* pending left sibling; v as described at the top of the file */
+        const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
+        stk[w.sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
+        ++w.sp;
+        w.cur = right;
+    } else if (pushR) {
+        w.cur = right;
+    } else if (pushL) {
+        w.cur = left;
+    } else {
+        w.alive = walk_pop(w, stk);
+    }
+}
+
+/* Visit of the leaf the lane stands on: its triangles in stored order (reference :359-368). */
+template <bool COUNT, bool ANYHIT>
+SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
+{
+    const uint32_t first = w.cur & 0x00FFFFFFu;
+    const uint32_t cnt = (w.cur >> 24) & 0x7Fu;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        if (COUNT)
+            st.tri += 1;
+        if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, w.T)) {
+            w.C = min_std(w.C, w.T);
+            w.hitTri = first + k;
+        }
+    }
+    if (ANYHIT && w.T < 0.99f && w.C != SRT_FLT_MAX)
+        w.alive = false;
+    else
+        w.alive = walk_pop(w, stk);
+}
+
+/* One trip of the wave: vote, then the kind of step more live lanes are waiting for.  Returns false when no
+ * lane of the wave has a query in flight. */
+template <bool CULL, bool COUNT, bool FAST, bool ANYHIT>
+SRT_DI bool walk_trip(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
+{
+    const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
+    const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
+    const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
+    if ((mInner | mLeaf) == 0)
+        return false;
+    if (__popcll(mInner) >= __popcll(mLeaf)) {
+        if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mInner) - 1)
+            st.wave_inner += 1;
+        if (atInner)
+            walk_inner<CULL, COUNT, FAST>(sc, w, stk, st);
+    } else {
+        if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mLeaf) - 1)
+            st.wave_leaf += 1;
+        if (atLeaf)
+            walk_leaf<COUNT, ANYHIT>(sc, w, stk, st);
+    }
+    return true;
+}
+
 template <bool CULL, bool COUNT, bool FAST, bool ANYHIT>
 SRT_DI bool traverse_loop(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
-    float C = SRT_FLT_MAX;
-    RayRcp rr = { 0, 0, 0 };
-    if (FAST)
-        rr.x = refined_rcp(d.x), rr.y = refined_rcp(d.y), rr.z = refined_rcp(d.z);
-    float val;
-    bool inside;
-    bool pass = FAST ? slab_test_fast(sc.root_lo, sc.root_hi, o, d, rr, T, val, inside) : slab_test(sc.root_lo, sc.root_hi, o, d, T, val, inside);
-    if (COUNT)
-        st.box += 1;
-    bool alive = val < C && (pass || !CULL);
-    uint32_t cur = sc.root_ref;
-    int sp = 0;
-    /* next pending left sibling that the reference would not skip at pop; false when the stack is empty */
-    auto pop = [&]() -> bool {
-        while (sp > 0) {
-            --sp;
-            const uint2 en = stk[sp * SRT_BLOCK];
-            if (!(__uint_as_float(en.y) > C)) {
-                cur = en.x;
-                return true;
-            }
-        }
-        return false;
-    };
-    for (;;) {
-        const bool atLeaf = alive && (cur & SRT_LEAF_FLAG);
-        const bool atInner = alive && !(cur & SRT_LEAF_FLAG);
-        const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
-        if ((mInner | mLeaf) == 0)
-            break;
-        if (__popcll(mInner) >= __popcll(mLeaf)) {
-            if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mInner) - 1)
-                st.wave_inner += 1;
-            if (atInner) {
-                if (COUNT) {
-                    st.inner += 1;
-                    st.box += 2;
-                }
-                const float4* nd = sc.nodes + 4ull * cur;
-                const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
-                const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
-                const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
-                const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
-                float lval, rval;
-                bool lin, rin;
-                const bool lpass = FAST ? slab_test_fast(llo, lhi, o, d, rr, T, lval, lin) : slab_test(llo, lhi, o, d, T, lval, lin);
-                const bool rpass = FAST ? slab_test_fast(rlo, rhi, o, d, rr, T, rval, rin) : slab_test(rlo, rhi, o, d, T, rval, rin);
-                const bool pushL = lval < C && (lpass || !CULL);
-                const bool pushR = rval < C && (rpass || !CULL);
-                if (pushL && pushR) {
-                    /* pending left sibling; v as described at the top of the file */
-                    const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
-                    stk[sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
-                    ++sp;
-                    cur = right;
-                } else if (pushR) {
-                    cur = right;
-                } else if (pushL) {
-                    cur = left;
-                } else {
-                    alive = pop();
-                }
-            }
-        } else {
-            if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mLeaf) - 1)
-                st.wave_leaf += 1;
-            if (atLeaf) {
-                const uint32_t first = cur & 0x00FFFFFFu;
-                const uint32_t cnt = (cur >> 24) & 0x7Fu;
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    if (COUNT)
-                        st.tri += 1;
-                    if (tri_test(sc.tris + 6ull * (first + k), o, d, T)) {
-                        C = min_std(C, T);
-                        hitTri = first + k;
-                    }
-                }
-                if (ANYHIT && T < 0.99f && C != SRT_FLT_MAX)
-                    alive = false;
-                else
-                    alive = pop();
-            }
-        }
+    Walk w;
+    walk_begin<CULL, COUNT, FAST>(sc, w, o, d, T, st);
+    while (walk_trip<CULL, COUNT, FAST, ANYHIT>(sc, w, stk, st)) {
     }
-    return C != SRT_FLT_MAX;
+    T = w.T;
+    hitTri = w.hitTri;
+    return w.C != SRT_FLT_MAX;
+}
+
+/* Operands for which slab_test_fast / div_by are exact (srt_device.h). */
+SRT_DI bool ray_in_fast_range(const SceneDev& sc, f3 o, f3 d)
+{
+    return sc.fast_boxes && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z) && coord_in_fast_range(o.x)
+        && coord_in_fast_range(o.y) && coord_in_fast_range(o.z);
 }
 
 template <bool CULL, bool COUNT, bool ANYHIT>
 SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     /* one decision per wave: every lane's operands in the ranges div_by is exact for, or plain division for all */
-    const bool ok = sc.fast_boxes && dir_in_fast_range(d.x) && dir_in_fast_range(d.y) && dir_in_fast_range(d.z) && coord_in_fast_range(o.x)
-        && coord_in_fast_range(o.y) && coord_in_fast_range(o.z);
-    if (__all(ok))
+    if (__all(ray_in_fast_range(sc, o, d)))
         return traverse_loop<CULL, COUNT, true, ANYHIT>(sc, o, d, T, hitTri, stk, st);
     return traverse_loop<CULL, COUNT, false, ANYHIT>(sc, o, d, T, hitTri, stk, st);
 }
@@ -370,27 +418,10 @@ SRT_DI void light_sample(const srt_light* L, uint32_t seed, uint32_t path, uint3
     }
 }
 
-/* testVisibilityLightSample, reference src/light.cpp:43-74 (the shadow flags are known to be set here) */
-template <bool CULL, bool COUNT>
-SRT_DI bool light_visible(const SceneDev& sc, uint32_t features, f3 samplePos, f3 ip, uint2* stk, Stats& st, uint32_t& nShadow)
-{
-    if (ip.x == samplePos.x && ip.y == samplePos.y && ip.z == samplePos.z)
-        return true;
-    f3 dir = samplePos - ip;
-    f3 org = ip + normalize3(dir) * 0.001f;
-    float T = 1.0f;
-    uint32_t tri;
-    nShadow += 1;
-    /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
-    if (bvh_query<CULL, COUNT, true>(sc, features, org, dir, T, tri, stk, st) && T < 0.99f)
-        return false;
-    return true;
-}
-
 /* The shade kernel's half: lights and samples in the reference's order; vis holds this hit's visibility bits
- * starting at bit index bit0. */
+ * (one byte each) starting at index bit0. */
 SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t seed, uint32_t path, uint32_t depth, f3 o, f3 d, float T,
-                             const Surface& s, const unsigned long long* __restrict__ vis, unsigned long long bit0)
+                             const Surface& s, const unsigned char* __restrict__ vis, unsigned long long bit0)
 {
     if (!(features & SRT_F_SHADING))
         return s.kd;
@@ -405,7 +436,7 @@ SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t see
             light_sample(L, seed, path, depth, li, 0, pos, col);
             const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
             if (n) {
-                const float v = ((vis[bit >> 6] >> (bit & 63)) & 1ull) ? 1.0f : 0.0f;
+                const float v = vis[bit] ? 1.0f : 0.0f;
                 res = res + sh * v;
                 bit += 1;
             } else {
@@ -417,7 +448,7 @@ SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t see
                 f3 pos, col;
                 light_sample(L, seed, path, depth, li, k, pos, col);
                 const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
-                const float v = ((vis[bit >> 6] >> (bit & 63)) & 1ull) ? 1.0f : 0.0f;
+                const float v = vis[bit] ? 1.0f : 0.0f;
                 res = res + sh * v;
                 bit += 1;
             }
@@ -596,44 +627,89 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 }
 
 /* Shadow queries of one recursion depth: item i = hit (i / shadows_per_hit), shadow sample (i % shadows_per_hit)
- * in the order the reference's light loop issues them.  The 64 lanes of a wave hold consecutive samples of
- * (mostly) one hit: same origin, neighbouring targets on the light, so they walk the tree together.  The wave
- * writes its 64 answers as one word (bit = visible). */
+ * in the order the reference's light loop issues them; the answer is one byte per item (1 = visible).
+ *
+ * Shadow queries differ wildly in length (an occluded one stops at its first hit, a free one walks every box
+ * around its origin), so a wave that started 64 of them together would soon run mostly empty.  Instead a
+ * lane whose query ends hands in its answer and, as soon as a quarter of the wave is idle, the idle lanes are
+ * given the wave's next items.  A wave draws its items from 64-item chunks at a fixed stride, consecutive items
+ * going to consecutive idle lanes, so its lanes keep working on neighbouring samples of the same few hits
+ * (same origin, nearby targets on the light).  Rays outside the ranges of the fast slab test (srt_device.h) are
+ * answered on the spot by the plain-division walk. */
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
-                                                              const float4* cur_paths, unsigned long long* vis, uint32_t shadows_per_hit,
-                                                              DevCounters* cnt)
+                                                              const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt)
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShadow = 0;
+    const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long n = (unsigned long long)(*hq_count) * shadows_per_hit;
     const unsigned long long stride = (unsigned long long)gridDim.x * SRT_BLOCK;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
-        const unsigned long long i = base + (threadIdx.x & 63u);
-        bool visible = false;
-        if (i < n) {
-            const uint32_t h = (uint32_t)(i / shadows_per_hit);
-            uint32_t k = (uint32_t)(i - (unsigned long long)h * shadows_per_hit);
-            uint32_t li = 0;
-            for (; li < sc.n_lights; ++li) {
-                const uint32_t c = shadow_samples(sc.lights[li].type, rp.features);
-                if (k < c)
-                    break;
-                k -= c;
+    unsigned long long chunk = (unsigned long long)blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); /* wave-uniform */
+    uint32_t used = 0;                                                                             /* items taken from it */
+    Walk w;
+    w.alive = false;
+    w.cur = 0, w.sp = 0, w.T = 1.0f, w.C = SRT_FLT_MAX, w.hitTri = 0;
+    unsigned long long item = 0;
+    bool busy = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const bool more = chunk < n;
+        if (more && __popcll(idle) >= 16) {
+            const uint32_t pos = used + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const unsigned long long mine = chunk + (unsigned long long)(pos >> 6) * stride + (pos & 63u);
+            used += (uint32_t)__popcll(idle);
+            chunk += (unsigned long long)(used >> 6) * stride;
+            used &= 63u;
+            if (!busy && mine < n) {
+                item = mine;
+                const uint32_t h = (uint32_t)(item / shadows_per_hit);
+                uint32_t k = (uint32_t)(item - (unsigned long long)h * shadows_per_hit);
+                uint32_t li = 0;
+                for (; li < sc.n_lights; ++li) {
+                    const uint32_t c = shadow_samples(sc.lights[li].type, rp.features);
+                    if (k < c)
+                        break;
+                    k -= c;
+                }
+                f3 o, d, thr;
+                float T;
+                uint32_t tri, sample, path;
+                hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
+                f3 pos3, col;
+                light_sample(sc.lights + li, rp.seed, path, (uint32_t)depth, li, k, pos3, col);
+                /* testVisibilityLightSample, reference src/light.cpp:54-62 */
+                const f3 ip = o + d * T;
+                if (ip.x == pos3.x && ip.y == pos3.y && ip.z == pos3.z) {
+                    vis[item] = 1;
+                } else {
+                    const f3 dir = pos3 - ip;
+                    const f3 org = ip + normalize3(dir) * 0.001f;
+                    nShadow += 1;
+                    if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
+                        walk_begin<CULL, COUNT, true>(sc, w, org, dir, 1.0f, st);
+                        busy = true;
+                    } else {
+                        float Ts = 1.0f;
+                        uint32_t ht;
+                        const bool hit = (rp.features & SRT_F_ACCEL) ? traverse_loop<CULL, COUNT, false, true>(sc, org, dir, Ts, ht, stk, st)
+                                                                     : traverse_linear<COUNT>(sc, org, dir, Ts, ht, st);
+                        vis[item] = (hit && Ts < 0.99f) ? 0 : 1;
+                    }
+                }
             }
-            f3 o, d, thr;
-            float T;
-            uint32_t tri, sample, path;
-            hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
-            f3 pos, col;
-            light_sample(sc.lights + li, rp.seed, path, (uint32_t)depth, li, k, pos, col);
-            visible = light_visible<CULL, COUNT>(sc, rp.features, pos, o + d * T, stk, st, nShadow);
         }
-        const unsigned long long word = __ballot(visible);
-        if ((threadIdx.x & 63u) == 0)
-            vis[base >> 6] = word;
+        const bool in_flight = walk_trip<CULL, COUNT, true, true>(sc, w, stk, st);
+        if (busy && !w.alive) {
+            /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
+            vis[item] = (w.C != SRT_FLT_MAX && w.T < 0.99f) ? 0 : 1;
+            busy = false;
+        }
+        /* nothing in flight: either items remain (every lane is idle now, so the next pass refills) or the wave is done */
+        if (!in_flight && chunk >= n)
+            break;
     }
     flush_counters(cnt, 0, nShadow, 0, st);
 }
@@ -642,7 +718,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_shadow(SceneDev sc, RenderD
  * reference's Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is accumulated front to back as
  * Lo_0 + (ks_0) * Lo_1 + (ks_0 * ks_1) * Lo_2 + ...; identical for paths of at most one bounce. */
 __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count, const float4* cur_paths,
-                                                       float4* next_paths, uint32_t* next_count, float* acc, const unsigned long long* vis,
+                                                       float4* next_paths, uint32_t* next_count, float* acc, const unsigned char* vis,
                                                        uint32_t shadows_per_hit, DevCounters* cnt)
 {
     Stats st = { 0, 0, 0, 0, 0 };
@@ -1162,9 +1238,8 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const bool timing = (flags & SRT_RENDER_TIMING) != 0;
     const uint32_t n = rp.n_samples;
     const uint32_t sph = shadows_per_hit(sc, rp.features);
-    /* one visibility bit per (hit, shadow sample), written as whole 64-bit words */
-    const unsigned long long vis_words = ((unsigned long long)n * sph + 63ull) / 64ull + 1ull;
-    int rc = d->vis.reserve((size_t)vis_words * 8);
+    /* one visibility byte per (hit, shadow sample); every sample of the rectangle may hit */
+    int rc = d->vis.reserve((size_t)n * sph + 64);
     if (rc != SRT_OK)
         return rc;
     int g_primary = 0, g_secondary = 0, g_shadow = 0, g_shade = 0;
@@ -1185,7 +1260,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     uint32_t* hq_count = d->qcounts;
     uint32_t* path_count = d->qcounts + 32;
     float* acc = (float*)d->acc.p;
-    unsigned long long* vis = (unsigned long long*)d->vis.p;
+    unsigned char* vis = (unsigned char*)d->vis.p;
     HIPCHK(hipMemsetAsync(d->qcounts, 0, 64 * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
     mark(d, st, 0, timing);
@@ -1201,7 +1276,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
-            acc, (const unsigned long long*)vis, sph, d->counters + 2);
+            acc, (const unsigned char*)vis, sph, d->counters + 2);
         if (depth == last_depth)
             break;
         mark(d, st, 1, timing);
