@@ -139,10 +139,8 @@ def main():
     t_build = time.perf_counter() - t_build
     cam = srt.make_camera(W, H)
 
+    tiling = importlib.import_module("simple-ray-tracer_amd.distributed")
     tw, th = args.tile if args.tile else ((W, H) if world == 1 else (480, 270))
-    rects = srt.tile_rects(W, H, tw, th)
-    n_tiles = len(rects)
-    tile_px = tw * th
     counter = None
     if world > 1:
         name = f"/srt_tiles_{os.environ.get('MASTER_PORT', '0')}"
@@ -151,79 +149,24 @@ def main():
         dist.barrier()
         if rank != 0:
             counter = srt.TileCounter(name, False)
-
+    tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter)
+    n_tiles = tiler.n_tiles
     stream = torch.cuda.current_stream()
-    tiles_buf = torch.zeros((n_tiles, th, tw, 3), dtype=torch.float32, device=dev)
-    frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
-    my_ids = torch.full((n_tiles,), -1, dtype=torch.int32)
 
-    def render_frame(step, flags):
-        """Draw tiles until the frame's counter runs out; at most two tiles in flight per rank so that a slow
-        tile on one GPU leaves the remaining tiles to the others."""
-        k = 0
-        events = []
-        while True:
-            t = counter.next(step) if counter else k
-            if t >= n_tiles:
-                break
-            if len(events) >= 2:
-                events[-2].synchronize()
-            p = bvh.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rects[t], flags)
-            x0, y0, x1, y1 = rects[t]
-            bvh.render_device(p, tiles_buf[k].data_ptr(), tw, th, x0, y0, stream.cuda_stream)
-            if world > 1:
-                ev = torch.cuda.Event()
-                ev.record(stream)
-                events.append(ev)
-            my_ids[k] = t
-            k += 1
-        return k
-
-    def place(ids, tiles):
-        """Tile-local buffers (top row first) into the Screen-layout frame on rank 0."""
-        for j, t in enumerate(ids):
-            x0, y0, x1, y1 = rects[t]
-            frame[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]
-
-    def gather(k):
-        """Finished tiles to rank 0: counts and ids by all_gather (a few hundred bytes), pixels by one
-        point-to-point transfer per peer over its direct xGMI link."""
-        if world == 1:
-            if n_tiles == 1 and (tw, th) == (W, H):
-                frame.copy_(tiles_buf[0])
-            else:
-                place(my_ids[:k].tolist(), tiles_buf)
-            return
-        meta = torch.full((n_tiles + 1,), -1, dtype=torch.int32, device=dev)
-        meta[0] = k
-        meta[1:k + 1] = my_ids[:k].to(dev)
-        metas = [torch.empty_like(meta) for _ in range(world)]
-        dist.all_gather(metas, meta)
-        if rank == 0:
-            counter.reset(step_slot[0] + 1)
-            host_meta = torch.stack(metas).cpu()
-            bufs, ops = {}, []
-            for r in range(1, world):
-                kr = int(host_meta[r, 0])
-                if kr:
-                    bufs[r] = torch.empty((kr, th, tw, 3), dtype=torch.float32, device=dev)
-                    ops.append(dist.P2POp(dist.irecv, bufs[r], r))
-            reqs = dist.batch_isend_irecv(ops) if ops else []
-            place(my_ids[:k].tolist(), tiles_buf)
-            for q in reqs:
-                q.wait()
-            for r, b in bufs.items():
-                place(host_meta[r, 1:1 + len(b)].tolist(), b)
-        elif k:
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, tiles_buf[:k].contiguous(), 0)]):
-                q.wait()
-
-    step_slot = [0]
+    def stream_fence():
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
 
     def one_step(flags):
-        k = render_frame(step_slot[0], flags)
-        gather(k)
-        step_slot[0] += 1
+        """One frame: this rank's share of the tiles (enqueued on the current stream, written straight into the
+        rank's tile buffer in HBM), then the gather to rank 0."""
+        def render_tile(rect, slot):
+            p = bvh.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rect, flags)
+            bvh.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], stream.cuda_stream)
+
+        k = tiler.render(render_tile, stream_fence if world > 1 else None)
+        tiler.gather(k)
         return k
 
     def fence():

@@ -434,8 +434,3 @@ class TileCounter:
             host().srth_tilecounter_close(self.h)
             self.h = None
 
-
-def tile_rects(width, height, tile_w, tile_h):
-    """Tiles of the frame in row-major order (y up, as the render loops count); edge tiles may be smaller."""
-    return [(x, y, min(x + tile_w, width), min(y + tile_h, height))
-            for y in range(0, height, tile_h) for x in range(0, width, tile_w)]
