@@ -15,8 +15,10 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(HERE, "csrc", "libsrt_hip.so")
-HOST_LIB = os.path.join(HERE, "host", "libsrt_host.so")
+# SRT_LIB_ROOT points at another build of the same two libraries (kernel A/B experiments); default: in-tree
+LIB_ROOT = os.environ.get("SRT_LIB_ROOT", HERE)
+HIP_LIB = os.path.join(LIB_ROOT, "csrc", "libsrt_hip.so")
+HOST_LIB = os.path.join(LIB_ROOT, "host", "libsrt_host.so")
 
 # feature bits (include/srt_hip.h)
 F_SHADING = 1 << 0

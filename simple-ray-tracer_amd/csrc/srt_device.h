@@ -14,7 +14,9 @@
 #include "../../include/srt_hip.h"
 
 #define SRT_FLT_MAX 3.402823466e+38f
+#ifndef SRT_BLOCK
 #define SRT_BLOCK 256
+#endif
 
 struct f3 {
     float x, y, z;
