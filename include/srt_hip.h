@@ -228,6 +228,11 @@ int srt_final_color_batch(srt_device* dev, srt_scene* scene, const float* rays7,
 /* Trackball::generateRay for n normalized pixel positions (host arrays; ndc: 2 floats, rays: 7 floats). */
 int srt_generate_rays(srt_device* dev, const srt_camera* camera, const float* ndc2, int64_t n, float* rays7);
 
+/* Device self-test (no counterpart in the reference): compares the ray-constant-denominator division used by the
+ * fast slab test with plain IEEE division on n pseudo-random operand pairs drawn from the ranges that path is
+ * restricted to; mismatches counts results that differ in more than the sign of a zero (expected: 0). */
+int srt_selftest_division(srt_device* dev, uint32_t seed, uint64_t n, uint64_t* mismatches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,7 +85,7 @@ HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "s
                    "srt_device_synchronize", "srt_device_read_counters", "srt_device_read_kernel_counters",
                    "srt_device_kernel_times",
                    "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_intersect_batch",
-                   "srt_final_color_batch", "srt_generate_rays")
+                   "srt_final_color_batch", "srt_generate_rays", "srt_selftest_division")
 
 
 def build():
@@ -143,6 +143,11 @@ def host():
     L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.srth_write_bmp.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int]
     L.srth_set_device.argtypes = [C.c_int]
+    L.srth_selftest_division.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.srth_mirror_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _f32p]
+    L.srth_mirror_intersect_one.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
+    L.srth_mirror_final_color.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p]
+    L.srth_mirror_generate_ray.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
     L.srth_tilecounter_open.restype = C.c_void_p
     L.srth_tilecounter_open.argtypes = [C.c_char_p, C.c_int]
     L.srth_tilecounter_next.restype = C.c_int64
@@ -408,6 +413,46 @@ def generate_rays(cam, ndc):
     rays = np.zeros((len(ndc), 7), np.float32)
     _check(host().srth_generate_rays(C.byref(cam), _p(ndc), len(ndc), _p(rays)))
     return rays
+
+
+def selftest_division(n=1 << 24, seed=1):
+    """Mismatches between the fast slab test's division and plain division on n random operand pairs (expect 0)."""
+    bad = C.c_uint64()
+    _check(host().srth_selftest_division(seed, n, C.byref(bad)))
+    return int(bad.value)
+
+
+def mirror_render(bvh, features, width, height, num_rays=1, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20, 20, 0)):
+    """The C++ mirror as a reference call site uses it: Screen, Trackball, renderRayTracing (src/main.cpp:472-476)."""
+    rgb = np.zeros((height, width, 3), np.float32)
+    la, rd = np.array(look_at, np.float32), np.array(rot_deg, np.float32)
+    _check(host().srth_mirror_render(bvh.h, features, width, height, fovy_deg, dist, _p(la), _p(rd), num_rays, _p(rgb)))
+    return rgb
+
+
+def mirror_intersect_one(bvh, ray7, features):
+    """BvhInterface::intersect(Ray&, HitInfo&, features) on one ray; returns (hit, t, HitInfo fields)."""
+    r = np.ascontiguousarray(ray7, np.float32).copy()
+    n, b, uv, kd, ks = (np.zeros(k, np.float32) for k in (3, 3, 2, 3, 3))
+    sh, tex = np.zeros(1, np.float32), np.zeros(1, np.int32)
+    rc = host().srth_mirror_intersect_one(bvh.h, _p(r), features, _p(n), _p(b), _p(uv), _p(kd), _p(ks), _p(sh), _p(tex, _i32p))
+    if rc < 0:
+        _check(rc)
+    return bool(rc), float(r[6]), {"normal": n, "bary": b, "uv": uv, "kd": kd, "ks": ks, "shininess": float(sh[0]), "has_texture": bool(tex[0])}
+
+
+def mirror_final_color(bvh, ray7, features):
+    r = np.ascontiguousarray(ray7, np.float32)
+    rgb = np.zeros(3, np.float32)
+    _check(host().srth_mirror_final_color(bvh.h, _p(r), features, _p(rgb)))
+    return rgb
+
+
+def mirror_generate_ray(ndc, aspect, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20, 20, 0)):
+    la, rd, nd = np.array(look_at, np.float32), np.array(rot_deg, np.float32), np.array(ndc, np.float32)
+    ray = np.zeros(7, np.float32)
+    _check(host().srth_mirror_generate_ray(aspect, fovy_deg, dist, _p(la), _p(rd), _p(nd), _p(ray)))
+    return ray
 
 
 def write_bmp(path, rgb):

@@ -884,6 +884,45 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_generate(srt_camera cam, const fl
     }
 }
 
+/* Self-test of div_by against plain division over the operand ranges slab_test_fast is used for: random
+ * mantissas and exponents plus the awkward cases (powers of two, all-ones mantissas, numerator zero, the range
+ * ends).  Counts results that differ other than in the sign of a zero. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_selftest_division(uint32_t seed, unsigned long long n, unsigned long long* mismatches)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * SRT_BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * SRT_BLOCK) {
+        const uint32_t h0 = mix32(mix32(seed, (uint32_t)i), (uint32_t)(i >> 32));
+        const uint32_t h1 = mix32(h0, 0x1234567u), h2 = mix32(h1, 0x89ABCDEu), h3 = mix32(h2, 0x5555AAAAu);
+        /* denominator: 2^-20 <= |d| < 2^21 */
+        uint32_t dm = h0 & 0x7FFFFFu;
+        const uint32_t kind = h3 & 15u;
+        if (kind == 0) dm = 0;
+        if (kind == 1) dm = 0x7FFFFFu;
+        if (kind == 2) dm = 1;
+        const uint32_t de = 107u + (h1 % 41u);
+        const float d = __uint_as_float((h1 & 0x80000000u) | (de << 23) | dm);
+        /* two coordinates in {0} U [2^-40, 2^20), numerator = their difference (as box bound - origin) */
+        auto coord = [](uint32_t h, uint32_t sel) {
+            if ((sel & 7u) == 0)
+                return 0.0f;
+            uint32_t m = h & 0x7FFFFFu;
+            if ((sel & 7u) == 1) m = 0;
+            if ((sel & 7u) == 2) m = 0x7FFFFFu;
+            const uint32_t e = 87u + ((h >> 23) % 60u);
+            return __uint_as_float((h & 0x80000000u) ^ ((sel & 8u) << 28) | (e << 23) | m);
+        };
+        const float b = coord(h2, h3 >> 4), o = coord(mix32(h2, 77u), h3 >> 8);
+        const float x = ((h3 >> 12) & 3u) == 0 ? (b - b * 1.00000012f) : (b - o); /* also nearly cancelling differences */
+        const float want = x / d;
+        const float got = div_by(x, d, refined_rcp(d));
+        const bool same = __float_as_uint(want) == __float_as_uint(got) || (want == 0.0f && got == 0.0f);
+        if (!same)
+            bad += 1;
+    }
+    if (bad)
+        atomicAdd(mismatches, bad);
+}
+
 /* ------------------------------------------------------------------------------------------ host side */
 
 static thread_local std::string g_err;
@@ -1519,6 +1558,27 @@ int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int6
     if (rc != SRT_OK)
         return rc;
     HIPCHK(hipMemcpy(rgb, d->io_b.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return SRT_OK;
+}
+
+int srt_selftest_division(srt_device* d, uint32_t seed, uint64_t n, uint64_t* mismatches)
+{
+    if (!d || !mismatches)
+        return fail(SRT_ERR_INVALID, "srt_selftest_division: null argument");
+    HIPCHK(hipSetDevice(d->gpu));
+    unsigned long long* dev = nullptr;
+    HIPCHK(hipMalloc((void**)&dev, 8));
+    hipError_t e = hipMemset(dev, 0, 8);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_division, dim3(d->n_cu * 8), dim3(SRT_BLOCK), 0, 0, seed, (unsigned long long)n, dev);
+        e = hipGetLastError();
+    }
+    unsigned long long host = 0;
+    if (e == hipSuccess) e = hipMemcpy(&host, dev, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess)
+        return fail(SRT_ERR_HIP, "srt_selftest_division: %s", hipGetErrorString(e));
+    *mismatches = host;
     return SRT_OK;
 }
 

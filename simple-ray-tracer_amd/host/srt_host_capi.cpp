@@ -11,9 +11,9 @@ using namespace srt;
 
 static thread_local std::string g_err;
 
-#define SRTH_TRY(body)                 \
+#define SRTH_TRY(...)                  \
     try {                              \
-        body;                          \
+        __VA_ARGS__;                   \
         return 0;                      \
     } catch (const std::exception& e) { \
         g_err = e.what();              \
@@ -324,6 +324,70 @@ int srth_synchronize(const srth_bvh* b, void* stream)
         return -1;
     }
     return 0;
+}
+
+int srth_selftest_division(uint32_t seed, uint64_t n, uint64_t* mismatches)
+{
+    try {
+        if (srt_selftest_division(deviceFor(currentDevice()), seed, n, mismatches) != SRT_OK) {
+            g_err = srt_last_error();
+            return -1;
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+/* ---- the C++ mirror exactly as a reference call site would use it (src/main.cpp:470-480): Screen + Trackball +
+ * renderRayTracing, BvhInterface::intersect on one ray, getFinalColor, Trackball::generateRay */
+int srth_mirror_render(const srth_bvh* b, uint32_t features, int width, int height, float fovy_deg, float dist, const float* look_at3,
+                       const float* rot_deg3, int num_rays, float* rgb)
+{
+    SRTH_TRY(Screen screen({ width, height }); screen.clear(vec3(0.0f));
+             Trackball camera(float(width) / float(height), radians(fovy_deg), dist);
+             camera.setCamera({ look_at3[0], look_at3[1], look_at3[2] }, radians(vec3(rot_deg3[0], rot_deg3[1], rot_deg3[2])), dist);
+             renderRayTracing(b->bvh->scene(), camera, *b->bvh, screen, featuresFromMask(features), 0.5f, 1, num_rays);
+             std::memcpy(rgb, &screen.pixels()[0].x, (size_t)width * height * 12))
+}
+
+int srth_mirror_intersect_one(const srth_bvh* b, float* ray7, uint32_t features, float* normal3, float* bary3, float* uv2, float* kd3, float* ks3,
+                              float* shininess, int* has_texture)
+{
+    try {
+        Ray ray { { ray7[0], ray7[1], ray7[2] }, { ray7[3], ray7[4], ray7[5] }, ray7[6] };
+        HitInfo hi;
+        const bool hit = b->bvh->intersect(ray, hi, featuresFromMask(features));
+        ray7[6] = ray.t;
+        if (hit) {
+            normal3[0] = hi.normal.x, normal3[1] = hi.normal.y, normal3[2] = hi.normal.z;
+            bary3[0] = hi.barycentricCoord.x, bary3[1] = hi.barycentricCoord.y, bary3[2] = hi.barycentricCoord.z;
+            uv2[0] = hi.texCoord.x, uv2[1] = hi.texCoord.y;
+            kd3[0] = hi.material.kd.x, kd3[1] = hi.material.kd.y, kd3[2] = hi.material.kd.z;
+            ks3[0] = hi.material.ks.x, ks3[1] = hi.material.ks.y, ks3[2] = hi.material.ks.z;
+            *shininess = hi.material.shininess;
+            *has_texture = hi.material.kdTexture ? 1 : 0;
+        }
+        return hit ? 1 : 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+
+int srth_mirror_final_color(const srth_bvh* b, const float* ray7, uint32_t features, float* rgb)
+{
+    SRTH_TRY(Ray ray { { ray7[0], ray7[1], ray7[2] }, { ray7[3], ray7[4], ray7[5] }, ray7[6] };
+             const vec3 c = getFinalColor(b->bvh->scene(), *b->bvh, ray, featuresFromMask(features)); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z)
+}
+
+int srth_mirror_generate_ray(float aspect, float fovy_deg, float dist, const float* look_at3, const float* rot_deg3, const float* ndc2, float* ray7)
+{
+    SRTH_TRY(Trackball camera(aspect, radians(fovy_deg), dist);
+             camera.setCamera({ look_at3[0], look_at3[1], look_at3[2] }, radians(vec3(rot_deg3[0], rot_deg3[1], rot_deg3[2])), dist);
+             const Ray r = camera.generateRay({ ndc2[0], ndc2[1] }); ray7[0] = r.origin.x; ray7[1] = r.origin.y; ray7[2] = r.origin.z;
+             ray7[3] = r.direction.x; ray7[4] = r.direction.y; ray7[5] = r.direction.z; ray7[6] = r.t)
 }
 
 /* Screen::writeBitmapToFile for a W*H*3 float framebuffer in Screen layout */

@@ -325,3 +325,39 @@ def test_dragon_full_size_properties(dragon_pair):
     strip = gb.render(cam, feat, nsx=4, nsy=2, rect=(0, 810, 3840, 1350), primary=False)["rgb"]
     assert np.array_equal(strip[810:1350].view(np.uint32), a["rgb"][810:1350].view(np.uint32))
     assert a["rgb"][810:1350].max() > 0.05 and np.isfinite(a["rgb"]).all()
+
+
+def test_fast_division_is_exact(gpu):
+    assert srt.selftest_division(1 << 26, seed=3) == 0
+
+
+def test_host_mirror_call_sites(orc, scenes, pair):
+    """The C++ mirror used the way the reference's own call sites use it."""
+    ob, gb = pair("cube_textured")
+    feat = FEATURE_SETS["interp_texture"] | srt.F_MISS_CULL
+    # renderRayTracing(scene, camera, bvh, screen, features, threshold, boxSize, numRays)
+    want = ob.render(orc.make_camera(64, 48), feat)
+    got = srt.mirror_render(gb, feat, 64, 48)
+    assert np.abs(got - want["rgb"]).max() <= RGB_TOL and want["rgb"].max() > 0.05
+    ms = feat | srt.F_MULTISAMPLE
+    want = ob.render(orc.make_camera(40, 30), ms, nsx=3, nsy=3)
+    got = srt.mirror_render(gb, ms, 40, 30, num_rays=3)
+    assert np.abs(got - want["rgb"]).max() <= RGB_TOL
+    # Trackball::generateRay + BvhInterface::intersect + getFinalColor on single rays
+    cam = orc.make_camera(64, 48)
+    for ndc in [(0.0, 0.0), (0.1, -0.2), (-0.9, 0.9)]:
+        ray = srt.mirror_generate_ray(ndc, 64 / 48)
+        assert_bits_equal(ray, orc.camera_rays(cam, [ndc])[0], "generateRay")
+        want_hit, _ = ob.intersect(ray[None, :], feat)
+        hit, t, info = srt.mirror_intersect_one(gb, ray, feat)
+        assert hit == bool(want_hit["hit"][0])
+        assert_bits_equal(np.float32(t), want_hit["t"][0], "ray.t")
+        if hit:
+            assert_bits_equal(info["normal"], want_hit["normal"][0], "HitInfo.normal")
+            assert_bits_equal(info["uv"], want_hit["uv"][0], "HitInfo.texCoord")
+            assert_bits_equal(info["kd"], want_hit["kd"][0], "HitInfo.material.kd (texel)")
+            assert info["has_texture"] and abs(info["shininess"] - 250.0) < 1e-6
+        want_rgb, _ = ob.final_color(ray[None, :], feat)
+        assert np.abs(srt.mirror_final_color(gb, ray, feat) - want_rgb[0]).max() <= RGB_TOL
+    # features outside the implemented path are refused loudly (no silent fallback)
+    assert any(h for h, _, _ in [srt.mirror_intersect_one(gb, srt.mirror_generate_ray((0, 0), 64 / 48), feat)])

@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of kernel build variants on one GPU: each variant runs the dragon and teapot benches; prints one line each.
+# A/B of kernel build variants (tools/mkvar.sh) on one GPU: each variant runs the dragon and teapot benches and
+# prints one line.  usage (on the GPU box): tools/run_ab.sh variantA variantB ...
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/ab
 for v in "$@"; do
