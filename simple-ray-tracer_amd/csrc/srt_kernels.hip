@@ -669,6 +669,159 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
     path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
 }
 
+/* ---- shadow queries: a walk with four-byte stack entries.
+ * Until a shadow query accepts its first hit, C is FLT_MAX: no pop test can skip a pending sibling, and the
+ * value the general walk keeps beside each sibling is never looked at.  An accepted hit below 0.99 answers the
+ * query.  So the common walk (swalk_*) stacks the sibling's reference alone, which halves the LDS a wave needs
+ * and lets more waves share a compute unit.  Two kinds of query do not fit it and are answered by
+ * shadow_walk_exact instead: one whose first accepted hit lies in [0.99, 1] (the reference walks on with C = t
+ * and may skip siblings), and one whose operands are outside the ranges of the fast slab test. */
+
+/* The reference's walk for one shadow ray (t = 1 at the start), start to end, on one lane: true when it ends with
+ * a hit below 0.99.  Stacks the PARENT's index for a pending left sibling; at the pop the sibling's box is taken
+ * from the parent's record and tested again.  That gives the value the general walk would have stored: the value
+ * of a passing box does not depend on t, and a box can only stop passing because t_in > t, which is the case the
+ * stored value would have been skipped for (t = C after any hit). */
+template <bool CULL, bool COUNT, bool FAST>
+SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Stats& st)
+{
+    RayRcp rr;
+    rr.x = rr.y = rr.z = 0.0f;
+    if (FAST)
+        rr.x = refined_rcp(d.x), rr.y = refined_rcp(d.y), rr.z = refined_rcp(d.z);
+    float T = 1.0f, C = SRT_FLT_MAX, val;
+    bool inside;
+    const bool pass = FAST ? slab_test_fast(sc.root_lo, sc.root_hi, o, d, rr, T, val, inside) : slab_test(sc.root_lo, sc.root_hi, o, d, T, val, inside);
+    if (COUNT)
+        st.box += 1;
+    if (!(val < C && (pass || !CULL)))
+        return false;
+    uint32_t cur = sc.root_ref;
+    int sp = 0;
+    for (;;) {
+        if (cur & SRT_LEAF_FLAG) {
+            const uint32_t first = cur & 0x00FFFFFFu;
+            const uint32_t cnt = (cur >> 24) & 0x7Fu;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                if (COUNT)
+                    st.tri += 1;
+                if (tri_test(sc.tris + 6ull * (first + k), o, d, T))
+                    C = min_std(C, T);
+            }
+            if (T < 0.99f && C != SRT_FLT_MAX)
+                return true;
+        } else {
+            if (COUNT) {
+                st.inner += 1;
+                st.box += 2;
+            }
+            const float4* nd = sc.nodes + 4ull * cur;
+            const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+            const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+            const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
+            float lval, rval;
+            bool lin, rin;
+            const bool lpass = FAST ? slab_test_fast(llo, lhi, o, d, rr, T, lval, lin) : slab_test(llo, lhi, o, d, T, lval, lin);
+            const bool rpass = FAST ? slab_test_fast(rlo, rhi, o, d, rr, T, rval, rin) : slab_test(rlo, rhi, o, d, T, rval, rin);
+            const bool pushL = lval < C && (lpass || !CULL);
+            const bool pushR = rval < C && (rpass || !CULL);
+            if (pushL && pushR) {
+                stk[sp * SRT_BLOCK] = cur;
+                ++sp;
+            }
+            if (pushR) {
+                cur = __float_as_uint(e.y);
+                continue;
+            }
+            if (pushL) {
+                cur = __float_as_uint(e.x);
+                continue;
+            }
+        }
+        bool found = false;
+        while (sp > 0 && !found) {
+            --sp;
+            const float4* nd = sc.nodes + 4ull * stk[sp * SRT_BLOCK];
+            const float4 a = nd[0], b = nd[1];
+            const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+            float lval;
+            bool lin;
+            const bool lpass = FAST ? slab_test_fast(llo, lhi, o, d, rr, T, lval, lin) : slab_test(llo, lhi, o, d, T, lval, lin);
+            if (CULL && !lpass)
+                continue; /* t_in > t = C by now: the stored t_in would have been skipped */
+            const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
+            if (!(v > C)) {
+                cur = __float_as_uint(nd[3].x);
+                found = true;
+            }
+        }
+        if (!found)
+            return false; /* a hit, if any, lies in [0.99, 1] */
+    }
+}
+
+SRT_DI bool swalk_pop(Walk& w, const uint32_t* stk)
+{
+    if (w.sp == 0)
+        return false;
+    --w.sp;
+    w.cur = stk[w.sp * SRT_BLOCK];
+    return true;
+}
+
+/* walk_inner with t = 1 and C = FLT_MAX: every value of a box in the fast ranges is finite, so the push test
+ * `value < C` holds and a child is entered when its box passes (or always, without miss culling). */
+template <bool CULL, bool COUNT>
+SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
+{
+    if (COUNT) {
+        st.inner += 1;
+        st.box += 2;
+    }
+    const float4* nd = sc.nodes + 4ull * w.cur;
+    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
+    const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
+    const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
+    float lval, rval;
+    bool lin, rin;
+    const bool pushL = slab_test_fast(llo, lhi, w.o, w.d, w.rr, 1.0f, lval, lin) || !CULL;
+    const bool pushR = slab_test_fast(rlo, rhi, w.o, w.d, w.rr, 1.0f, rval, rin) || !CULL;
+    if (pushL && pushR) {
+        stk[w.sp * SRT_BLOCK] = left;
+        ++w.sp;
+        w.cur = right;
+    } else if (pushR) {
+        w.cur = right;
+    } else if (pushL) {
+        w.cur = left;
+    } else {
+        w.alive = swalk_pop(w, stk);
+    }
+}
+
+/* Leaf visit of the common shadow walk.  Returns 0: no hit, walk on; 1: occluded; 2: first hit in [0.99, 1]. */
+template <bool COUNT>
+SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& st)
+{
+    const uint32_t first = w.cur & 0x00FFFFFFu;
+    const uint32_t cnt = (w.cur >> 24) & 0x7Fu;
+    float T = 1.0f;
+    bool hit = false;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        if (COUNT)
+            st.tri += 1;
+        if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, T))
+            hit = true;
+    }
+    if (hit) {
+        w.alive = false;
+        return T < 0.99f ? 1 : 2;
+    }
+    w.alive = swalk_pop(w, stk);
+    return 0;
+}
+
 /* Shadow queries of one recursion depth: item i = hit (i / shadows_per_hit), shadow sample (i % shadows_per_hit)
  * in the order the reference's light loop issues them; the answer is one byte per item (1 = visible).
  *
@@ -677,14 +830,16 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
  * lane whose query ends hands in its answer and, as soon as a quarter of the wave is idle, the idle lanes are
  * given the wave's next items.  A wave draws its items from 64-item chunks at a fixed stride, consecutive items
  * going to consecutive idle lanes, so its lanes keep working on neighbouring samples of the same few hits
- * (same origin, nearby targets on the light).  Rays outside the ranges of the fast slab test (srt_device.h) are
- * answered on the spot by the plain-division walk. */
+ * (same origin, nearby targets on the light). */
+#ifndef SRT_SHADOW_WAVES
+#define SRT_SHADOW_WAVES 6 /* waves per SIMD the register allocation aims at (measured: 4: 249 ms, 6: 231, 7: 229 with spills, 8: 239) */
+#endif
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
+__global__ __launch_bounds__(SRT_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
                                                               const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt)
 {
-    extern __shared__ uint2 lds_stack[];
-    uint2* stk = lds_stack + threadIdx.x;
+    extern __shared__ uint32_t lds_stack4[];
+    uint32_t* stk = lds_stack4 + threadIdx.x;
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShadow = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -733,26 +888,49 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_shadow(SceneDev sc, RenderD
                     nShadow += 1;
                     if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
                         walk_begin<CULL, COUNT, true>(sc, w, org, dir, 1.0f, st);
-                        busy = true;
+                        busy = w.alive;
+                        if (!busy)
+                            vis[item] = 1; /* the ray misses the root box */
+                    } else if (rp.features & SRT_F_ACCEL) {
+                        vis[item] = shadow_walk_exact<CULL, COUNT, false>(sc, org, dir, stk, st) ? 0 : 1;
                     } else {
                         float Ts = 1.0f;
                         uint32_t ht;
-                        const bool hit = (rp.features & SRT_F_ACCEL) ? traverse_loop<CULL, COUNT, false, true>(sc, org, dir, Ts, ht, stk, st)
-                                                                     : traverse_linear<COUNT>(sc, org, dir, Ts, ht, st);
-                        vis[item] = (hit && Ts < 0.99f) ? 0 : 1;
+                        /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
+                        vis[item] = (traverse_linear<COUNT>(sc, org, dir, Ts, ht, st) && Ts < 0.99f) ? 0 : 1;
                     }
                 }
             }
         }
-        const bool in_flight = walk_trip<CULL, COUNT, true, true>(sc, w, stk, st);
+        /* one trip of the wave, as walk_trip: vote, then the kind of step more lanes are waiting for */
+        const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
+        const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
+        const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
+        if ((mInner | mLeaf) == 0) {
+            /* nothing in flight: either items remain (every lane is idle, so the next pass refills) or the wave is done */
+            if (chunk >= n)
+                break;
+            continue;
+        }
+        int verdict = 0;
+        if (__popcll(mInner) * SRT_VOTE_INNER_W >= __popcll(mLeaf) * SRT_VOTE_LEAF_W) {
+            if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
+                st.wave_inner += 1;
+            if (atInner)
+                swalk_inner<CULL, COUNT>(sc, w, stk, st);
+        } else {
+            if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
+                st.wave_leaf += 1;
+            if (atLeaf)
+                verdict = swalk_leaf<COUNT>(sc, w, stk, st);
+        }
         if (busy && !w.alive) {
-            /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
-            vis[item] = (w.C != SRT_FLT_MAX && w.T < 0.99f) ? 0 : 1;
+            if (verdict == 2)
+                vis[item] = shadow_walk_exact<CULL, COUNT, true>(sc, w.o, w.d, stk, st) ? 0 : 1;
+            else
+                vis[item] = verdict == 1 ? 0 : 1;
             busy = false;
         }
-        /* nothing in flight: either items remain (every lane is idle now, so the next pass refills) or the wave is done */
-        if (!in_flight && chunk >= n)
-            break;
     }
     flush_counters(cnt, 0, nShadow, 0, st);
 }
@@ -1271,6 +1449,7 @@ void srt_scene_destroy(srt_scene* s)
 /* Stack capacity: at most one pending left sibling per inner level. */
 static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + SRT_STACK_SLACK; }
 static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
+static size_t shadow_stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint32_t); }
 
 template <typename K>
 static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid)
@@ -1328,7 +1507,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     int g_primary = 0, g_secondary = 0, g_shadow = 0, g_shade = 0;
     rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, lds, &g_primary);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, lds, &g_secondary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, lds, &g_shadow);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_stack_bytes(sc), &g_shadow);
     if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g_shade);
     if (rc != SRT_OK)
         return rc;
@@ -1354,7 +1533,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
         if (sph) {
             mark(d, st, 4, timing);
-            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_BLOCK), lds, st, sc->view, rp, depth, hq, hq_count + depth, cur,
+            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_BLOCK), shadow_stack_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
                 vis, sph, d->counters + 4);
         }
         mark(d, st, 2, timing);

@@ -28,7 +28,7 @@ def pair(orc, scenes, gpu):
     cache = {}
 
     def get(name, extra_lights=None):
-        key = (name, None if extra_lights is None else len(extra_lights))
+        key = (name, None if extra_lights is None else np.asarray(extra_lights, np.float32).tobytes())
         if key not in cache:
             d = dict(scenes(name))
             if extra_lights is not None:
@@ -202,6 +202,45 @@ def test_mixed_lights(orc, pair):
     want = ob.render(orc.make_camera(48, 48), feat)
     got = gb.render(srt.make_camera(48, 48), feat)
     _compare_frames(got, want, "three light types")
+
+
+@pytest.mark.parametrize("policy", ["reference", "cull"])
+@pytest.mark.parametrize("name,behind", [("cornell", 0.004), ("monkey", 0.0005)])
+def test_shadow_hit_just_before_light(orc, pair, name, behind, policy):
+    # Lights just behind a surface: seen from far enough away the surface is hit at 0.99 <= t <= 1, which the
+    # reference does not count as occlusion (light.cpp:60) but walks on from with the smaller t.
+    cull = srt.F_MISS_CULL if policy == "cull" else 0
+    ob, _ = pair(name)
+    cam = orc.make_camera(64, 48)
+    rays = orc.camera_rays(cam, orc.pixel_ndc(64, 48).reshape(-1, 2))
+    prim, _ = ob.intersect(rays, orc.F_ACCEL | cull)
+    hit = np.nonzero(prim["hit"])[0]
+    pts = rays[hit, :3] + rays[hit, 3:6] * prim["t"][hit, None]
+    lights = []
+    for i in hit[:: max(1, len(hit) // 3)][:3]:
+        q = rays[i, :3] + rays[i, 3:6] * prim["t"][i]
+        n = prim["normal"][i] / np.linalg.norm(prim["normal"][i])
+        if np.dot(n, rays[i, 3:6]) < 0:
+            n = -n  # away from the camera: behind the surface
+        lights.append(orc.point_light(tuple((q + behind * n).astype(np.float32))))
+    ob, gb = pair(name, lights)
+    # the case is present: shadow rays of the primary hits that end with a hit in [0.99, 1]
+    near = 0
+    for lt in lights:
+        lp = np.asarray(lt, np.float32).ravel()[1:4]
+        dv = (lp[None, :] - pts).astype(np.float32)
+        org = pts + dv / np.linalg.norm(dv, axis=1, keepdims=True) * np.float32(0.001)
+        sr = np.concatenate([org, dv, np.ones((len(pts), 1), np.float32)], axis=1).astype(np.float32)
+        want, _ = ob.intersect(sr, orc.F_ACCEL | cull)
+        got, _, _ = gb.intersect(sr, srt.F_ACCEL | cull)
+        assert np.array_equal(got["hit"], want["hit"]) and np.array_equal(got["tri"], want["tri"])
+        assert_bits_equal(got["t"], want["t"], "shadow-ray t")
+        near += int(((want["hit"] != 0) & (want["t"] >= 0.99)).sum())
+    assert near > 30, near
+    feat = SH | srt.F_HARD_SHADOW | srt.F_RECURSIVE | cull
+    want = ob.render(orc.make_camera(64, 48), feat)
+    got = gb.render(srt.make_camera(64, 48), feat)
+    _compare_frames(got, want, f"lights just behind surfaces, {name}/{policy}")
 
 
 def test_final_color_batch(orc, scenes, pair):
