@@ -171,12 +171,13 @@ SRT_DI bool tri_test(const float4* __restrict__ rec, f3 o, f3 d, float& T)
     const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
     const f3 v0 = xyz(q1), v1 = xyz(q2), v2 = mk3(q3.x, q3.y, q3.z);
     const f3 c0 = mk3(q3.w, q4.x, q4.y), c1 = mk3(q4.z, q4.w, q5.x), c2 = mk3(q5.y, q5.z, q5.w);
-    /* sameSide(p, v0, v1, v2) && sameSide(p, v1, v0, v2) && sameSide(p, v2, v0, v1) */
-    if (!(dot3(cross3(v2 - v1, p - v1), c0) >= 0))
-        return false;
-    if (!(dot3(cross3(v2 - v0, p - v0), c1) >= 0))
-        return false;
-    if (!(dot3(cross3(v1 - v0, p - v0), c2) >= 0))
+    /* sameSide(p, v0, v1, v2) && sameSide(p, v1, v0, v2) && sameSide(p, v2, v0, v1).  All three are evaluated
+     * (no short circuit): the record's five remaining quarters are then fetched together and waited for once,
+     * instead of in three dependent rounds; the lanes of a wave rarely agree on an early exit anyway. */
+    const bool s0 = dot3(cross3(v2 - v1, p - v1), c0) >= 0;
+    const bool s1 = dot3(cross3(v2 - v0, p - v0), c1) >= 0;
+    const bool s2 = dot3(cross3(v1 - v0, p - v0), c2) >= 0;
+    if (!(s0 & s1 & s2))
         return false;
     T = nt;
     return true;
