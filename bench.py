@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU, 480x270 otherwise)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -164,10 +166,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: this benchmark measures the HIP path and has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     srt = importlib.import_module("simple-ray-tracer_amd")
     srt.set_device(local_rank)
@@ -193,7 +200,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     def stream_fence():
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=True)
         ev.record(stream)
         return ev
 

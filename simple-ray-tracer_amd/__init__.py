@@ -180,7 +180,7 @@ class Scene:
         self._keep = []
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and host is not None:  # module globals are gone at interpreter exit
             host().srth_scene_destroy(self.h)
             self.h = None
 
@@ -275,7 +275,7 @@ class HostBvh:
             raise SrtError(host().srth_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and host is not None:  # module globals are gone at interpreter exit
             host().srth_hostbvh_destroy(self.h)
             self.h = None
 
@@ -320,7 +320,7 @@ class Bvh:
             raise SrtError(host().srth_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and host is not None:  # module globals are gone at interpreter exit
             host().srth_bvh_destroy(self.h)
             self.h = None
 

@@ -48,9 +48,13 @@ def main():
     counts = torch.tensor(taken, dtype=torch.int64)
     all_counts = [torch.zeros_like(counts) for _ in range(world)]
     dist.all_gather(all_counts, counts)
+    order = torch.tensor(ft.order, dtype=torch.int64)
+    all_orders = [torch.zeros_like(order) for _ in range(world)]
+    dist.all_gather(all_orders, order)
     if rank == 0:
         whole = bvh.render(cam, feat, threads=1, primary=False)["rgb"]
-        np.savez(out_path, frame=ft.frame.numpy(), whole=whole, counts=torch.stack(all_counts).numpy(), n_tiles=ft.n_tiles)
+        np.savez(out_path, frame=ft.frame.numpy(), whole=whole, counts=torch.stack(all_counts).numpy(), n_tiles=ft.n_tiles,
+                 orders=torch.stack(all_orders).numpy())
     dist.barrier()
     counter.close()
     dist.destroy_process_group()

@@ -66,3 +66,13 @@ def test_two_ranks_gloo(tmp_path):
     counts = z["counts"]  # [rank, frame]
     assert (counts.sum(0) == int(z["n_tiles"])).all()  # every frame: all tiles, none twice
     assert z["whole"].max() > 0.05
+    orders = z["orders"]  # next frame's hand-out order as each rank derived it from the gathered tile times
+    assert (orders == orders[0]).all() and sorted(orders[0].tolist()) == list(range(int(z["n_tiles"])))
+
+
+def test_hand_out_order():
+    ft = tiling.FrameTiler(100, 72, 32, 24, "cpu")  # 4 x 3 tiles
+    assert sorted(ft.order) == list(range(12))
+    assert ft.order[0] == 5 and ft.order[-1] in (3, 11)  # the centre tile first, a far corner last
+    ft._reorder([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [5, 1, 1, 9, 1, 1, 7, 1, 1, 1, 1, 1])
+    assert ft.order[:3] == [3, 6, 0] and ft.order[3:] == [1, 2, 4, 5, 7, 8, 9, 10, 11]
