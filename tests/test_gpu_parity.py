@@ -366,6 +366,50 @@ def test_dragon_full_size_properties(dragon_pair):
     assert a["rgb"][810:1350].max() > 0.05 and np.isfinite(a["rgb"]).all()
 
 
+@pytest.mark.parametrize("name,max_depth,policy", [("cube_textured", 5, "cull"), ("cube_textured", 4, "reference"), ("monkey", 5, "cull"),
+                                                   ("monkey", 4, "cull"), ("monkey", 5, "reference")])
+def test_textured_recursive_full_size(orc, pair, name, max_depth, policy):
+    """Textured cube and monkey at 1920 x 1080 with normal interpolation, texture lookup and mirror recursion
+    (depth cap 5 as the reference has it, and 4): whole frames against the oracle."""
+    ob, gb = pair(name)
+    feat = FEATURE_SETS["interp_texture"] | (srt.F_MISS_CULL if policy == "cull" else 0)
+    want = ob.render(orc.make_camera(1920, 1080), feat, max_depth=max_depth)
+    got = gb.render(srt.make_camera(1920, 1080), feat, max_depth=max_depth)
+    _compare_frames(got, want, f"{name} 1920x1080 depth {max_depth} {policy}")
+    wc, gc = want["counters"], got["counters"]
+    assert (gc["path_rays"], gc["shadow_rays"], gc["shaded_hits"]) == (wc["path_rays"], wc["shadow_rays"], wc["shaded_hits"])
+
+
+@pytest.mark.parametrize("max_depth", [1, 5])
+def test_cornell_1024(orc, pair, max_depth):
+    """Cornell box 1024 x 1024, hard shadows and mirror reflection (one bounce, and the reference's cap of 5), under
+    the reference's visiting rule; at depth 5 the ray total is the one recorded from the reference run."""
+    ob, gb = pair("cornell")
+    feat = FEATURE_SETS["recursive"]
+    want = ob.render(orc.make_camera(1024, 1024), feat, max_depth=max_depth)
+    got = gb.render(srt.make_camera(1024, 1024), feat, max_depth=max_depth)
+    _compare_frames(got, want, f"cornell 1024 depth {max_depth}")
+    gc = got["counters"]
+    assert gc["path_rays"] == want["counters"]["path_rays"] and gc["shadow_rays"] == want["counters"]["shadow_rays"]
+    if max_depth == 5:
+        assert gc["path_rays"] + gc["shadow_rays"] == 1328237
+
+
+def test_dragon_8k_64spp_window(orc, dragon_pair):
+    """A window of the 7680 x 4320, 64 spp (8 x 8 grid) stress frame: sample numbering and the sampler keys of a
+    2.1-G-sample frame, against the oracle on the same window."""
+    d, ob, gb = dragon_pair
+    feat = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_MISS_CULL
+    rect = (4004, 3690, 4052, 3714)  # across the upper silhouette; ragged against the 8 x 8-pixel sample blocks
+    want = ob.render(orc.make_camera(7680, 4320), feat, nsx=8, nsy=8, rect=rect)
+    got = gb.render(srt.make_camera(7680, 4320), feat, nsx=8, nsy=8, rect=rect)
+    ys, xs = slice(4320 - rect[3], 4320 - rect[1]), slice(rect[0], rect[2])
+    sub = lambda r: {k: (v[ys, xs] if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+    _compare_frames(sub(got), sub(want), "8K 64 spp window")
+    assert got["counters"]["path_rays"] == want["counters"]["path_rays"] == 48 * 24 * 64
+    assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
+
+
 def test_fast_division_is_exact(gpu):
     assert srt.selftest_division(1 << 26, seed=3) == 0
 
