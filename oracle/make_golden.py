@@ -8,6 +8,9 @@ checkout exists; the fixtures it writes are plain data (inputs and the reference
   tests/golden/leaf_math.npz       inputs and reference outputs of the leaf functions
   tests/golden/camera.npz          glm camera arithmetic as used by framework/src/trackball.cpp
   tests/golden/obj_cases/*.npz     the reference loader's output for the OBJ files authored in that directory
+  tests/golden/screen_bmp.npz      float pixels and the bytes of the .bmp file the reference's writer makes of them
+
+usage: make_golden.py [scenes|leaf|camera|obj|bmp ...]   (default: all)
 """
 import ctypes as C
 import os
@@ -224,11 +227,36 @@ def gen_obj_cases():
             print(f"{fn} normalize={normalize}: meshes={len(d['materials'])} verts={len(d['verts'])} tris={len(d['tris'])}")
 
 
+def gen_bitmap():
+    """stb's BMP writer fed as Screen::writeBitmapToFile feeds it (src/screen.cpp:93-104)."""
+    import tempfile
+    R = orc.ref()
+    rng = np.random.default_rng(11)
+    w, h = 7, 5  # odd sizes: no row padding exists in the 32-bit layout, and none must appear
+    rgb = (rng.random((h, w, 3)) * 1.6 - 0.3).astype(np.float32)  # some values below 0 and above 1
+    rgb[0, 0] = (0.0, 1.0, 0.5)
+    rgb[0, 1] = (254.999 / 255.0, 1.0 / 255.0, 0.999 / 255.0)  # truncation, not rounding
+    rgb[h - 1, w - 1] = (2.0, -1.0, 1.0)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "out.bmp")
+        assert R.ref_write_bmp(path.encode(), w, h, p(np.ascontiguousarray(rgb)))
+        data = np.frombuffer(open(path, "rb").read(), np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "screen_bmp.npz"), rgb=rgb, bmp=data)
+    print("bmp fixture:", len(data), "bytes")
+
+
 if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
-    scenes = gen_scenes()
-    gen_leaf(scenes)
-    gen_camera()
-    gen_obj_cases()
+    what = sys.argv[1:] or ["scenes", "leaf", "camera", "obj", "bmp"]
+    if "scenes" in what or "leaf" in what:
+        scenes = gen_scenes()
+        if "leaf" in what:
+            gen_leaf(scenes)
+    if "camera" in what:
+        gen_camera()
+    if "obj" in what:
+        gen_obj_cases()
+    if "bmp" in what:
+        gen_bitmap()
     print("golden fixtures written to", GOLD)

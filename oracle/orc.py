@@ -346,6 +346,7 @@ def ref():
         R.ref_reflection_ray.argtypes = [_f32p, _f32p, _f32p, C.c_long]
         R.ref_glm_camera.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p]
         R.ref_glm_camera_rays.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_long]
+        R.ref_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, _f32p]
         _ref = R
     return _ref
 

@@ -9,7 +9,8 @@
  *   framework/src/mesh.cpp  framework/src/image.cpp  third_party/tinyobjloader/src/tiny_obj_loader.cc
  * The BVH, light, render, screen and trackball units need the reference's OpenGL drawing / window code
  * (GL/glu.h, GLU, GLFW are not in this image); no substitute for those is written, so they are not linked.
- * For the camera, the glm header-only arithmetic that trackball.cpp uses is exercised directly.
+ * For the camera, the glm header-only arithmetic that trackball.cpp uses is exercised directly; for the bitmap
+ * file, the vendored stb_image_write.h and the glm conversion expression of src/screen.cpp:96-103.
  */
 #include "scene.h"
 #include "intersect.h"
@@ -24,6 +25,8 @@ DISABLE_WARNINGS_POP()
 #include <cstring>
 #include <limits>
 #include <vector>
+#define STB_IMAGE_WRITE_IMPLEMENTATION
+#include <stb/stb_image_write.h>
 
 static glm::vec3 g3(const float* p) { return glm::vec3(p[0], p[1], p[2]); }
 static Ray mkray(const float* r) { return Ray { g3(r), g3(r + 3), r[6] }; }
@@ -244,6 +247,15 @@ void ref_glm_camera_rays(float fovy_deg, float dist, const float* look_at3, cons
         const float r[7] = { o.x, o.y, o.z, d.x, d.y, d.z, std::numeric_limits<float>::max() };
         std::memcpy(out7 + 7 * i, r, sizeof r);
     }
+}
+
+/* What Screen::writeBitmapToFile (src/screen.cpp:93-104) hands to stb: clamp, scale by 255, convert to bytes. */
+int ref_write_bmp(const char* path, int w, int h, const float* rgb)
+{
+    std::vector<glm::u8vec4> px((size_t)w * h);
+    for (size_t i = 0; i < px.size(); ++i)
+        px[i] = glm::u8vec4(glm::vec4(glm::clamp(g3(rgb + 3 * i), 0.0f, 1.0f), 1.0f) * 255.0f);
+    return stbi_write_bmp(path, w, h, 4, px.data());
 }
 
 } // extern "C"

@@ -442,24 +442,29 @@ void Screen::clear(const vec3& color) { std::fill(m_textureData.begin(), m_textu
 void Screen::setPixel(int x, int y, const vec3& color) { m_textureData[(size_t)indexAt(x, y)] = color; }
 int Screen::indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
 
-/* writeBitmapToFile, reference src/screen.cpp:93-104: clamp to [0,1], scale by 255, truncate, opaque alpha;
- * 32-bit BMP, rows bottom-up. */
+/* writeBitmapToFile, reference src/screen.cpp:93-104: clamp to [0,1], scale by 255, truncate, opaque alpha, and
+ * the file stb_image_write makes of four-channel data (stb_image_write.h:501-509): BITMAPV4HEADER, 32 bits per
+ * pixel, BI_BITFIELDS with the masks of B,G,R,A byte order, rows bottom-up, every other header field zero. */
 void Screen::writeBitmapToFile(const std::filesystem::path& filePath)
 {
     const int w = m_resolution.x, h = m_resolution.y;
-    const uint32_t dataSize = (uint32_t)w * (uint32_t)h * 4u, headerSize = 14 + 40;
+    const uint32_t dataSize = (uint32_t)w * (uint32_t)h * 4u, headerSize = 14 + 108;
     std::vector<uint8_t> file(headerSize + dataSize, 0);
     auto put16 = [&](size_t at, uint16_t v) { file[at] = v & 255, file[at + 1] = v >> 8; };
     auto put32 = [&](size_t at, uint32_t v) { for (int k = 0; k < 4; ++k) file[at + k] = (v >> (8 * k)) & 255; };
     file[0] = 'B', file[1] = 'M';
     put32(2, headerSize + dataSize);
     put32(10, headerSize);
-    put32(14, 40);
+    put32(14, 108);
     put32(18, (uint32_t)w);
     put32(22, (uint32_t)h);
     put16(26, 1);
     put16(28, 32);
-    put32(34, dataSize);
+    put32(30, 3); /* BI_BITFIELDS */
+    put32(54, 0x00ff0000u);
+    put32(58, 0x0000ff00u);
+    put32(62, 0x000000ffu);
+    put32(66, 0xff000000u);
     auto to8 = [](float c) {
         const float cl = std::min(std::max(c, 0.0f), 1.0f);
         return (uint8_t)(cl * 255.0f);

@@ -153,3 +153,13 @@ def test_bmp_writer(tmp_path):
     px = np.frombuffer(b[off:], np.uint8).reshape(2, 3, 4)  # bottom row first, BGRA
     assert px[1, 0].tolist() == [0, 127, 255, 255]
     assert px[0, 2].tolist() == [255, 0, 254, 255]
+
+
+def test_bitmap_file_matches_reference_writer(tmp_path):
+    """Screen::writeBitmapToFile: byte for byte the file the reference's writer (stb_image_write behind the glm
+    conversion of src/screen.cpp:96-103) made of the same pixels."""
+    g = np.load(os.path.join(GOLD, "screen_bmp.npz"))
+    path = str(tmp_path / "out.bmp")
+    srt.write_bmp(path, g["rgb"])
+    got = np.frombuffer(open(path, "rb").read(), np.uint8)
+    assert got.shape == g["bmp"].shape and np.array_equal(got, g["bmp"])
