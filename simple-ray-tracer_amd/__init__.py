@@ -148,6 +148,8 @@ def host():
     L.srth_mirror_intersect_one.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
     L.srth_mirror_final_color.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p]
     L.srth_mirror_generate_ray.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+    L.srth_config_describe.restype = C.c_long
+    L.srth_config_describe.argtypes = [C.c_char_p, C.c_char_p, C.c_long]
     L.srth_tilecounter_open.restype = C.c_void_p
     L.srth_tilecounter_open.argtypes = [C.c_char_p, C.c_int]
     L.srth_tilecounter_next.restype = C.c_int64
@@ -453,6 +455,19 @@ def mirror_generate_ray(ndc, aspect, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0),
     ray = np.zeros(7, np.float32)
     _check(host().srth_mirror_generate_ray(aspect, fovy_deg, dist, _p(la), _p(rd), _p(nd), _p(ray)))
     return ray
+
+
+def config_describe(toml_text):
+    """The command-line front end's reading of a configuration text, printed as the reference prints its Config."""
+    n = host().srth_config_describe(toml_text.encode(), None, 0)
+    if n < 0:
+        raise SrtError(host().srth_last_error().decode())
+    buf = C.create_string_buffer(n)
+    host().srth_config_describe(toml_text.encode(), buf, n)
+    return buf.value.decode()
+
+
+CLI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "srt_render")
 
 
 def write_bmp(path, rgb):

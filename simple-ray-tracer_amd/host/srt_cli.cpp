@@ -1,0 +1,96 @@
+/*
+ * srt_cli.cpp -- command-line rendering: `srt_render config.toml`, the flow of the reference's
+ * `FinalProject config.toml` with command_line_rendering = true (src/main.cpp:434-491): read the configuration,
+ * load the scene, build the BVH, render one image per [[cameras]] entry and write
+ * <output_dir>/<scene>_<start time>_cam_<index>.bmp.  Rendering happens on the GPU; there is no interactive mode.
+ *
+ *   srt_render config.toml            render
+ *   srt_render --check config.toml    parse and print the configuration only (needs no GPU)
+ */
+#include "srt_config.h"
+
+#include <chrono>
+#include <cstdio>
+#include <ctime>
+#include <iostream>
+
+using namespace srt;
+
+int main(int argc, char** argv)
+{
+    try {
+        bool checkOnly = false;
+        const char* configPath = nullptr;
+        for (int i = 1; i < argc; ++i) {
+            if (std::string(argv[i]) == "--check")
+                checkOnly = true;
+            else
+                configPath = argv[i];
+        }
+        if (!configPath) {
+            std::cerr << "usage: srt_render [--check] config.toml   (without a configuration the reference opens its interactive viewer, "
+                         "which is not part of this program)\n";
+            return 2;
+        }
+        const Config config = readConfigFile(configPath);
+        std::cout << config;
+        if (checkOnly)
+            return 0;
+        if (!config.cliRenderingEnabled) {
+            std::cerr << "command_line_rendering = false asks for the interactive viewer, which is not part of this program\n";
+            return 2;
+        }
+        if (config.windowSize.x <= 0 || config.windowSize.y <= 0) {
+            std::cerr << "window_size must be an array of two positive integers\n";
+            return 2;
+        }
+        setDevice(config.backend.gpu);
+
+        Scene scene;
+        std::string sceneName;
+        if (const auto* path = std::get_if<std::filesystem::path>(&config.scene)) {
+            scene = loadSceneFromFile(*path, config.lights);
+            sceneName = path->stem().string();
+        } else {
+            const SceneType type = std::get<SceneType>(config.scene);
+            scene = loadScenePrebuilt(type, config.dataPath);
+            sceneName = serialize(type);
+        }
+        Features features = config.features;
+        features.enableSoftShadow = config.backend.enableSoftShadow;
+        BvhInterface bvh { &scene, features };
+
+        using clock = std::chrono::high_resolution_clock;
+        if (!std::filesystem::exists(config.outputDir))
+            std::filesystem::create_directories(config.outputDir);
+        const auto start = clock::now();
+        char startTime[64];
+        const std::time_t now = std::time(nullptr);
+        std::strftime(startTime, sizeof startTime, "%Y-%m-%d-%H:%M:%S", std::localtime(&now));
+
+        RenderOptions options;
+        options.referenceTraversal = config.backend.referenceTraversal;
+        options.maxDepth = config.backend.maxDepth;
+        options.seed = config.backend.seed;
+        /* The reference starts one host thread per camera; the frames of one GPU are stream ordered, so they are
+         * rendered one after the other here. */
+        int index = 0;
+        for (const CameraConfig& cameraConfig : config.cameras) {
+            Screen screen { config.windowSize, false };
+            screen.clear(vec3(0.0f));
+            Trackball camera { float(config.windowSize.x) / float(config.windowSize.y), radians(cameraConfig.fieldOfView), cameraConfig.distanceFromLookAt };
+            camera.setCamera(cameraConfig.lookAt, radians(cameraConfig.rotation), cameraConfig.distanceFromLookAt);
+            renderRayTracing(scene, camera, bvh, screen, features, config.backend.numRays, options);
+            const std::filesystem::path filepath = config.outputDir / (sceneName + "_" + startTime + "_cam_" + std::to_string(index) + ".bmp");
+            std::printf("Image %d saved to %s\n", index, filepath.string().c_str());
+            screen.writeBitmapToFile(filepath);
+            ++index;
+        }
+        const auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - start).count();
+        std::printf("Rendering took %lld ms, %zu images rendered.\n", (long long)duration, config.cameras.size());
+        return 0;
+    } catch (const std::exception& e) {
+        std::cerr << e.what() << "\n";
+        return 1;
+    }
+}

@@ -48,6 +48,8 @@ struct uvec3 {
 };
 struct ivec2 {
     int x = 0, y = 0;
+    int operator[](int i) const { return i == 0 ? x : y; }
+    int& operator[](int i) { return i == 0 ? x : y; }
 };
 
 struct Image {

@@ -5,6 +5,9 @@
 #include <cstring>
 #include <string>
 
+#include <sstream>
+
+#include "srt_config.h"
 #include "srt_host.h"
 
 using namespace srt;
@@ -454,6 +457,26 @@ void srth_tilecounter_close(srth_tilecounter* t)
     if (t->owner)
         shm_unlink(t->name.c_str());
     delete t;
+}
+
+/* Parses a configuration text as the command-line front end does and writes its printed form (the reference's
+ * `std::cout << config`) into out; returns the length needed (terminator included) or -1. */
+long srth_config_describe(const char* toml_text, char* out, long cap)
+{
+    try {
+        std::ostringstream os;
+        os << readConfigText(toml_text);
+        const std::string s = os.str();
+        if (out && cap > 0) {
+            const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+            std::memcpy(out, s.data(), n);
+            out[n] = 0;
+        }
+        return (long)s.size() + 1;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
 }
 
 } // extern "C"

@@ -79,6 +79,13 @@ def point_light(pos, col=(1, 1, 1)):
     return l
 
 
+def segment_light(e0, e1, c0, c1):
+    l = np.zeros(LIGHT_STRIDE, np.float32)
+    l[0] = 1
+    l[1:4], l[4:7], l[7:10], l[10:13] = e0, e1, c0, c1
+    return l
+
+
 def parallelogram_light(v0, e01, e02, c0, c1, c2, c3):
     l = np.zeros(LIGHT_STRIDE, np.float32)
     l[0] = 2

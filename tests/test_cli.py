@@ -1,0 +1,179 @@
+"""The command-line front end (`srt_render config.toml`, the reference's `FinalProject config.toml` flow of
+src/main.cpp:434-491) and its configuration reader (keys and quirks of src/config.cpp:192-374)."""
+import glob
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+srt = importlib.import_module("simple-ray-tracer_amd")
+
+BASE = """
+command_line_rendering = true
+window_size = [64, 48]
+data_path = "{data}"
+scene = "{scene}"
+output_dir = "{out}"
+[features]
+enable_shading = true
+enable_recursive = true
+enable_hard_shadow = true
+enable_normal_interp = true
+enable_texture_mapping = false
+enable_accel_structure = true
+"""
+
+CAMERAS = """
+[[cameras]]
+field_of_view = 50.0
+distance_from_look_at = 3.0
+look_at = [0.0, 0.0, 0.0]
+rotation = [20.0, 20.0, 0.0]
+
+[[cameras]]   # integers where the reference needs floats are accepted too
+field_of_view = 35
+distance_from_look_at = 4.5
+look_at = [0.1, -0.2, 0.3]
+rotation = [-33, 125.0, 10]
+"""
+
+LIGHTS = """
+[[lights]]
+type = "point"
+position = [-1.0, 1.5, -1.0]
+color = [1.0, 1.0, 1.0]
+[[lights]]
+type = "segment"
+endpoints = [[0.5, 1.0, -1.0], [-0.5, 1.0, -1.0]]
+colors = [[1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]
+[[lights]]
+type = "parallelogram"
+corner = [-0.2, 1.2, -0.2]
+edges = [[0.4, 0, 0], [0, 0, 0.4]]
+colors = [[1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 1, 1]]
+[[lights]]
+type = "disco"
+"""
+
+
+def _cfg(tmp_path, scene="quads_groups.obj"):
+    return BASE.format(data=os.path.join(GOLD, "obj_cases"), scene=scene, out=str(tmp_path / "out"))
+
+
+def test_config_keys_and_defaults(tmp_path):
+    text = srt.config_describe(_cfg(tmp_path) + CAMERAS + LIGHTS)
+    assert "+ window_size: 64, 48" in text and "enable_recursive: true" in text and "enable_texture_mapping: false" in text
+    assert "enable_soft_shadow: false" in text  # the reference's reader has no key for it
+    assert f'+ scene: "{os.path.join(GOLD, "obj_cases", "quads_groups.obj")}"' in text
+    assert "- field_of_view: 35\n      distance_from_look_at: 4.5\n      look_at: [0.1, -0.2, 0.3]\n      rotation: [-33, 125, 10]" in text
+    assert text.count("- type:") == 3 and "edge01: [0.4, 0, 0], edge02: [0, 0, 0.4]" in text  # the unknown type is skipped
+    assert "color2: [0, 0, 1], color3: [0, 1, 1]" in text and "endpoint0: [0.5, 1, -1], endpoint1: [-0.5, 1, -1]" in text
+
+
+def test_config_quirks_of_the_reference_reader(tmp_path):
+    # a camera without `rotation` gets zeros, not the (20, 20, 0) of CameraConfig: the reference's array helper
+    # returns an engaged optional for a missing array (src/config.cpp:150-169)
+    text = srt.config_describe(_cfg(tmp_path) + "[[cameras]]\nfield_of_view = 60.0\ndistance_from_look_at = 2.0\n")
+    assert "look_at: [0, 0, 0]\n      rotation: [0, 0, 0]" in text
+    # prebuilt scenes by name (any spelling the reference accepts) and by number
+    for spelling, printed in (("CornellBox", "CornellBox"), ("cube-textured", "CubeTextured"), ("TEAPOT", "Teapot")):
+        assert f"+ scene: SceneType::{printed}" in srt.config_describe(_cfg(tmp_path, spelling))
+    assert "+ scene: SceneType::Monkey" in srt.config_describe(_cfg(tmp_path).replace('scene = "quads_groups.obj"', "scene = 5"))
+    # a window_size that is not two integers leaves zeros
+    assert "+ window_size: 0, 0" in srt.config_describe(_cfg(tmp_path).replace("window_size = [64, 48]", "window_size = [64.0, 48.0]"))
+
+
+def test_config_errors(tmp_path):
+    with pytest.raises(srt.SrtError, match="does not exist"):
+        srt.config_describe(_cfg(tmp_path, "no_such_scene.obj"))
+    with pytest.raises(srt.SrtError, match="features.enable_hard_shadow"):
+        srt.config_describe(_cfg(tmp_path).replace("enable_hard_shadow = true\n", ""))
+    with pytest.raises(srt.SrtError, match="command_line_rendering"):
+        srt.config_describe(_cfg(tmp_path).replace("command_line_rendering = true", 'command_line_rendering = "yes"'))
+    with pytest.raises(srt.SrtError, match="line 3"):
+        srt.config_describe("a = 1\nb = 2\nc = = 3\n")
+    with pytest.raises(srt.SrtError, match="defined twice"):
+        srt.config_describe("a = 1\na = 2\n")
+    with pytest.raises(srt.SrtError, match="dates and times"):
+        srt.config_describe("when = 2024-05-01T10:00:00Z\n")
+
+
+def test_toml_syntax(tmp_path):
+    # dotted keys, inline tables, multi-line arrays with comments and a trailing comma, literal and multi-line strings,
+    # underscores and bases in integers, quoted keys
+    doc = '''
+cameras = [
+  { field_of_view = 4_5.0, distance_from_look_at = 0x3, look_at = [0, 0, 0], rotation = [1e1, -2.5E0, +0.0] },  # one
+  # two
+  { "field_of_view" = 50.0, 'distance_from_look_at' = 3.0, look_at = [
+      0.5,
+      0.25, # y
+      0.125,
+    ], rotation = [0, 0, 0] },
+]
+''' + _cfg(tmp_path).replace("[features]", "[features]\nextra.enable_multiple_rays_per_pixel = true") + '''
+[mi355x]
+num_rays = 3
+traversal = 'reference'
+enable_soft_shadow = true
+'''
+    text = srt.config_describe(doc)
+    assert "enable_multiple_rays_per_pixel: true" in text
+    assert "- field_of_view: 45\n      distance_from_look_at: 3\n      look_at: [0, 0, 0]\n      rotation: [10, -2.5, 0]" in text
+    assert "look_at: [0.5, 0.25, 0.125]" in text
+    assert "- num_rays: 3" in text and "- traversal: reference" in text and "+ mi355x: \n    - gpu: 0\n    - num_rays: 3\n    - enable_soft_shadow: true" in text
+
+
+def test_cli_check_mode(tmp_path):
+    cfg = tmp_path / "c.toml"
+    cfg.write_text(_cfg(tmp_path) + CAMERAS + LIGHTS)
+    r = subprocess.run([srt.CLI, "--check", str(cfg)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("Final Project Configurations: ") and "Unknown light type: disco -- Skip" in r.stderr
+    r = subprocess.run([srt.CLI], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage" in r.stderr
+    bad = tmp_path / "bad.toml"
+    bad.write_text("command_line_rendering = \n")
+    r = subprocess.run([srt.CLI, "--check", str(bad)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Failed parsing" in r.stderr and "line 1" in r.stderr
+
+
+def test_cli_without_gpu_fails_loudly(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = tmp_path / "c.toml"
+    cfg.write_text(_cfg(tmp_path) + CAMERAS + LIGHTS)
+    r = subprocess.run([srt.CLI, str(cfg)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    assert not glob.glob(str(tmp_path / "out" / "*.bmp"))
+
+
+@pytest.mark.gpu
+def test_cli_renders_what_the_library_renders(tmp_path):
+    """srt_render on an OBJ scene with lights from the configuration, two cameras: the bitmap files are byte for byte
+    what renderRayTracing + writeBitmapToFile give when called directly with the same parameters."""
+    srt.set_device(0)
+    cfg = tmp_path / "c.toml"
+    cfg.write_text(_cfg(tmp_path) + CAMERAS + LIGHTS)
+    r = subprocess.run([srt.CLI, str(cfg)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Image 0 saved to" in r.stdout and "Image 1 saved to" in r.stdout and "2 images rendered." in r.stdout
+    files = sorted(glob.glob(str(tmp_path / "out" / "quads_groups_*_cam_*.bmp")))
+    assert len(files) == 2 and files[0].endswith("_cam_0.bmp")
+    standin = importlib.import_module("simple-ray-tracer_amd.standin")
+    lights = [standin.point_light((-1.0, 1.5, -1.0)), standin.segment_light((0.5, 1.0, -1.0), (-0.5, 1.0, -1.0), (1, 0, 0), (0, 0, 1)),
+              standin.parallelogram_light((-0.2, 1.2, -0.2), (0.4, 0, 0), (0, 0, 0.4), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1))]
+    scene = srt.Scene.from_obj(os.path.join(GOLD, "obj_cases", "quads_groups.obj"), False, lights)
+    bvh = srt.Bvh(scene, srt.F_ACCEL)
+    feat = srt.F_ACCEL | srt.F_SHADING | srt.F_RECURSIVE | srt.F_HARD_SHADOW | srt.F_NORMAL_INTERP | srt.F_MISS_CULL
+    cams = [(50.0, 3.0, (0, 0, 0), (20, 20, 0)), (35.0, 4.5, (0.1, -0.2, 0.3), (-33, 125, 10))]
+    for path, (fov, dist, la, rot) in zip(files, cams):
+        rgb = srt.mirror_render(bvh, feat, 64, 48, 1, fov, dist, la, rot)
+        assert rgb.max() > 0.05
+        want = str(tmp_path / "want.bmp")
+        srt.write_bmp(want, rgb)
+        assert open(path, "rb").read() == open(want, "rb").read()
