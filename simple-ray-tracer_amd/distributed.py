@@ -132,11 +132,10 @@ class FrameTiler:
         if self.rank == 0:
             # arm the counter two frames ahead: no rank can be past frame step + 1 before the next gather
             self.counter.reset(self.step + 2)
-            bufs, reqs = {}, []
-            for r in range(1, self.world):
-                if counts[r]:
-                    bufs[r] = torch.empty((counts[r], self.th, self.tw, 3), dtype=torch.float32, device=self.device)
-                    reqs.append(dist.irecv(bufs[r], src=r))
+            bufs = {r: torch.empty((counts[r], self.th, self.tw, 3), dtype=torch.float32, device=self.device)
+                    for r in range(1, self.world) if counts[r]}
+            # one batch: the receives from all peers run side by side, each over its own link
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r) for r, b in bufs.items()]) if bufs else []
             self._place(self.ids[:k].tolist(), self.tiles)
             for q in reqs:
                 q.wait()
