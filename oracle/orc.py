@@ -120,6 +120,7 @@ def lib():
         L.orc_texel.argtypes = [_f32p, C.c_int32, C.c_int32, C.c_float, C.c_float, _f32p]
         L.orc_rand01.argtypes = [C.c_uint32] * 6
         L.orc_rand01.restype = C.c_float
+        L.orc_bloom.argtypes = [_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32]
         _lib = L
     return _lib
 
@@ -279,6 +280,13 @@ class Bvh:
                          _ptr(pm, _i32p) if primary else None, _ptr(pt, _i32p) if primary else None,
                          _ptr(tt, _f32p) if primary else None, threads, C.byref(cnt))
         return {"rgb": rgb, "mesh": pm, "tri": pt, "t": tt, "counters": cnt.as_dict()}
+
+
+def bloom(rgb, threshold, box_size):
+    """Screen::applyBloomFilter on a frame stored top row first; returns the filtered copy."""
+    out = np.ascontiguousarray(rgb, np.float32).copy()
+    lib().orc_bloom(_ptr(out, _f32p), out.shape[1], out.shape[0], threshold, box_size)
+    return out
 
 
 def make_camera(width, height, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20, 20, 0)):

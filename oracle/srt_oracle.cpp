@@ -22,6 +22,7 @@
 #include "srt_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -843,6 +844,40 @@ void orc_render(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, in
 float orc_rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim)
 {
     return rand01(seed, path, depth, light, sample, dim);
+}
+
+/* reference src/screen.cpp:32-78, in its own terms: a [width][height] table filled in storage order, thresholded
+ * (:45-55), box-filtered in place over the half-open window with the full box as divisor (:58-72) and added to the
+ * frame in the same pass (:74). */
+void orc_bloom(float* rgb, int32_t width, int32_t height, float threshold, int32_t box_size)
+{
+    std::vector<std::vector<std::array<float, 3>>> table((size_t)width, std::vector<std::array<float, 3>>((size_t)height));
+    size_t i = 0;
+    for (size_t w = 0; w < (size_t)width; w++)
+        for (size_t h = 0; h < (size_t)height; h++, i++) {
+            const float* px = rgb + 3 * i;
+            const float m = std::max(px[0], std::max(px[1], px[2]));
+            if (m > threshold)
+                table[w][h] = { px[0], px[1], px[2] };
+            else
+                table[w][h] = { 0.0f, 0.0f, 0.0f };
+        }
+    i = 0;
+    const int half = box_size / 2;
+    for (size_t w = 0; w < (size_t)width; w++)
+        for (size_t h = 0; h < (size_t)height; h++, i++) {
+            if (w >= (size_t)half && w < (size_t)(width - half) && h >= (size_t)half && h < (size_t)(height - half)) {
+                float sum[3] = { 0.0f, 0.0f, 0.0f };
+                for (size_t a = w - half; a < w + half; a++)
+                    for (size_t b = h - half; b < h + half; b++)
+                        for (int c = 0; c < 3; c++)
+                            sum[c] += table[a][b][c];
+                for (int c = 0; c < 3; c++)
+                    table[w][h][c] = sum[c] / float(box_size * box_size);
+            }
+            for (int c = 0; c < 3; c++)
+                rgb[3 * i + c] += table[w][h][c];
+        }
 }
 
 } // extern "C"

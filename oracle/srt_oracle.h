@@ -128,6 +128,9 @@ void orc_render(const orc_bvh*, const orc_camera* cam, uint32_t features, int32_
 
 /* Counter-based uniform sample in [0,1) shared with the device code. */
 float orc_rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim);
+/* Screen::applyBloomFilter (reference src/screen.cpp:32-78) on a frame stored top row first, in place.
+ * Parity unpinned: screen.cpp needs the OpenGL headers and cannot be built here. */
+void orc_bloom(float* rgb, int32_t width, int32_t height, float threshold, int32_t box_size);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ F_TEXTURE = 1 << 5
 F_ACCEL = 1 << 6
 F_MULTISAMPLE = 1 << 7
 F_SAH = 1 << 8           # host-side build option (extra.enableBvhSahBinning)
+F_BLOOM = 1 << 9         # host-side pass of the C++ mirror (extra.enableBloomEffect); not a kernel flag
 F_MISS_CULL = 1 << 16    # traversal policy; clear it for the reference's exact visiting rule
 
 RENDER_STATS = 1 << 0
@@ -148,6 +149,7 @@ def host():
     L.srth_mirror_intersect_one.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
     L.srth_mirror_final_color.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p]
     L.srth_mirror_generate_ray.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
+    L.srth_bloom.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_int]
     L.srth_config_describe.restype = C.c_long
     L.srth_config_describe.argtypes = [C.c_char_p, C.c_char_p, C.c_long]
     L.srth_tilecounter_open.restype = C.c_void_p
@@ -455,6 +457,13 @@ def mirror_generate_ray(ndc, aspect, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0),
     ray = np.zeros(7, np.float32)
     _check(host().srth_mirror_generate_ray(aspect, fovy_deg, dist, _p(la), _p(rd), _p(nd), _p(ray)))
     return ray
+
+
+def bloom(rgb, threshold, box_size):
+    """Screen::applyBloomFilter on a frame (top row first); returns the filtered copy."""
+    out = np.ascontiguousarray(rgb, np.float32).copy()
+    _check(host().srth_bloom(_p(out), out.shape[1], out.shape[0], threshold, box_size))
+    return out
 
 
 def config_describe(toml_text):

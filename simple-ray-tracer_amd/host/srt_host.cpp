@@ -440,6 +440,42 @@ Screen::Screen(const ivec2& resolution, bool)
 }
 void Screen::clear(const vec3& color) { std::fill(m_textureData.begin(), m_textureData.end(), color); }
 void Screen::setPixel(int x, int y, const vec3& color) { m_textureData[(size_t)indexAt(x, y)] = color; }
+
+/* applyBloomFilter, reference src/screen.cpp:32-78, with everything that makes its result what it is:
+ *  - the pixel array is walked in storage order but addressed as table[w][h] with w = i / height, h = i % height,
+ *    i.e. as a width x height array laid over the row-major height x width image;
+ *  - the window of a pixel is [w - half, w + half) x [h - half, h + half) (upper bounds excluded, (2 half)^2 values)
+ *    while the divisor is boxSize^2;
+ *  - the table is filtered in place, so window entries before the pixel (in walking order) are already filtered;
+ *  - pixels nearer than `half` to the table's border keep their thresholded value;
+ *  - the comparisons mix size_t and int as the reference does (a negative bound wraps to a huge one). */
+void Screen::applyBloomFilter(const float threshold, const int boxSize)
+{
+    const int W = m_resolution.x, H = m_resolution.y;
+    std::vector<vec3> bright(m_textureData.size());
+    for (size_t i = 0; i < bright.size(); ++i) {
+        const vec3& c = m_textureData[i];
+        const float maxColour = std::max(c.x, std::max(c.y, c.z));
+        bright[i] = maxColour > threshold ? c : vec3(0.0f);
+    }
+    const int half = boxSize / 2;
+    const float divisor = float(boxSize * boxSize);
+    size_t i = 0;
+    for (size_t w = 0; w < (size_t)W; ++w) {
+        for (size_t h = 0; h < (size_t)H; ++h, ++i) {
+            if (w >= (size_t)half && w < (size_t)(W - half) && h >= (size_t)half && h < (size_t)(H - half)) {
+                vec3 sum(0.0f);
+                for (size_t a = w - (size_t)half; a < w + (size_t)half; ++a)
+                    for (size_t b = h - (size_t)half; b < h + (size_t)half; ++b) {
+                        const vec3& t = bright[a * (size_t)H + b];
+                        sum.x += t.x, sum.y += t.y, sum.z += t.z;
+                    }
+                bright[i] = vec3(sum.x / divisor, sum.y / divisor, sum.z / divisor);
+            }
+            m_textureData[i].x += bright[i].x, m_textureData[i].y += bright[i].y, m_textureData[i].z += bright[i].z;
+        }
+    }
+}
 int Screen::indexAt(int x, int y) const { return (m_resolution.y - 1 - y) * m_resolution.x + x; }
 
 /* writeBitmapToFile, reference src/screen.cpp:93-104: clamp to [0,1], scale by 255, truncate, opaque alpha, and
@@ -561,7 +597,6 @@ static void rejectUnsupported(const Features& f)
     else if (f.extra.enableEnvironmentMapping) what = "environment mapping";
     else if (f.extra.enableMotionBlur) what = "motion blur";
     else if (f.extra.enableDepthOfField) what = "depth of field";
-    else if (f.extra.enableBloomEffect) what = "bloom";
     if (what)
         throw std::runtime_error(std::string("feature not implemented by the MI355X back end: ") + what);
 }
@@ -589,12 +624,18 @@ void renderRayTracing(const Scene&, const Trackball& camera, const BvhInterface&
     out.on_device = 0;
     if (srt_render(bvh.device(), bvh.deviceScene(), &p, &out, opt.stream) != SRT_OK)
         raise("renderRayTracing");
+    /* reference src/render.cpp:231-233; a host-side pass over the frame, as in the reference (sequential by construction) */
+    if (features.extra.enableBloomEffect && whole)
+        screen.applyBloomFilter(opt.bloomThreshold, 2 * opt.bloomBoxSize + 1);
 }
 
-void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const float&,
-                      const int&, const int& numRays)
+void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features,
+                      const float& threshold, const int& boxSize, const int& numRays)
 {
-    renderRayTracing(scene, camera, bvh, screen, features, numRays, RenderOptions {});
+    RenderOptions options;
+    options.bloomThreshold = threshold;
+    options.bloomBoxSize = boxSize;
+    renderRayTracing(scene, camera, bvh, screen, features, numRays, options);
 }
 
 vec3 getFinalColor(const Scene&, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth)

@@ -190,6 +190,8 @@ struct RenderOptions {
     int maxDepth = 5;                /* the reference hard-codes 5 (src/render.cpp:107) */
     int samplesX = 0, samplesY = 0;  /* 0: numRays x numRays as in the reference */
     uint32_t seed = 0;
+    float bloomThreshold = 0.5f;     /* what the reference's callers pass (src/main.cpp:39-42,476): threshold 0.5, */
+    int bloomBoxSize = 1;            /* boxSize 2 * 0 + 1; used only with extra.enableBloomEffect */
     int rect[4] = { 0, 0, 0, 0 };    /* x0,y0,x1,y1; all zero = whole frame */
     bool stats = false;
     bool timing = false;
@@ -277,6 +279,7 @@ class Screen {
 public:
     Screen(const ivec2& resolution, bool presentable = false);
     void clear(const vec3& color);
+    void applyBloomFilter(const float threshold, const int boxSize);
     void setPixel(int x, int y, const vec3& color);
     void writeBitmapToFile(const std::filesystem::path& filePath);
     [[nodiscard]] ivec2 resolution() const { return m_resolution; }

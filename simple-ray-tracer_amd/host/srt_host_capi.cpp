@@ -27,6 +27,7 @@ static thread_local std::string g_err;
     }
 
 #define SRTH_F_SAH (1u << 8) /* extra.enableBvhSahBinning; a host-side build option, not a kernel flag */
+#define SRTH_F_BLOOM (1u << 9) /* extra.enableBloomEffect; a host-side pass over the finished frame */
 
 static Features featuresFromMask(uint32_t m)
 {
@@ -40,6 +41,7 @@ static Features featuresFromMask(uint32_t m)
     f.enableAccelStructure = m & SRT_F_ACCEL;
     f.extra.enableMultipleRaysPerPixel = m & SRT_F_MULTISAMPLE;
     f.extra.enableBvhSahBinning = m & SRTH_F_SAH;
+    f.extra.enableBloomEffect = m & SRTH_F_BLOOM;
     return f;
 }
 
@@ -457,6 +459,13 @@ void srth_tilecounter_close(srth_tilecounter* t)
     if (t->owner)
         shm_unlink(t->name.c_str());
     delete t;
+}
+
+/* Screen::applyBloomFilter on a frame given top row first (Screen's storage order), in place. */
+int srth_bloom(float* rgb, int width, int height, float threshold, int box_size)
+{
+    SRTH_TRY(Screen screen({ width, height }); std::memcpy(&screen.pixels()[0].x, rgb, (size_t)width * height * 12);
+             screen.applyBloomFilter(threshold, box_size); std::memcpy(rgb, &screen.pixels()[0].x, (size_t)width * height * 12))
 }
 
 /* Parses a configuration text as the command-line front end does and writes its printed form (the reference's

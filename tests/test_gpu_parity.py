@@ -410,6 +410,17 @@ def test_dragon_8k_64spp_window(orc, dragon_pair):
     assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
 
 
+def test_bloom_through_the_mirror(orc, pair):
+    """renderRayTracing with extra.enableBloomEffect and the parameters the reference's callers pass (threshold 0.5,
+    boxSize 1 -> a 3-box): the frame, then Screen::applyBloomFilter on it."""
+    ob, gb = pair("cornell")
+    feat = FEATURE_SETS["recursive"] | srt.F_MISS_CULL
+    plain = ob.render(orc.make_camera(80, 60), feat)["rgb"]
+    want = orc.bloom(plain, 0.5, 3)
+    got = srt.mirror_render(gb, feat | srt.F_BLOOM, 80, 60)
+    assert np.abs(got - want).max() <= RGB_TOL * 2 and np.abs(want - plain).max() > 0.1
+
+
 def test_fast_division_is_exact(gpu):
     assert srt.selftest_division(1 << 26, seed=3) == 0
 

@@ -163,3 +163,33 @@ def test_bitmap_file_matches_reference_writer(tmp_path):
     srt.write_bmp(path, g["rgb"])
     got = np.frombuffer(open(path, "rb").read(), np.uint8)
     assert got.shape == g["bmp"].shape and np.array_equal(got, g["bmp"])
+
+
+def _bloom_by_hand(img, threshold, box):
+    """Screen::applyBloomFilter (reference src/screen.cpp:32-78) spelled out in Python on float32 scalars."""
+    H, W = img.shape[:2]
+    flat = img.reshape(-1, 3).astype(np.float32).copy()
+    table = [[flat[w * H + h].copy() if flat[w * H + h].max() > threshold else np.zeros(3, np.float32) for h in range(H)] for w in range(W)]
+    half = box // 2
+    for w in range(W):
+        for h in range(H):
+            if half <= w < W - half and half <= h < H - half:
+                acc = np.zeros(3, np.float32)
+                for a in range(w - half, w + half):
+                    for b in range(h - half, h + half):
+                        acc = (acc + table[a][b]).astype(np.float32)
+                table[w][h] = (acc / np.float32(box * box)).astype(np.float32)
+            flat[w * H + h] = (flat[w * H + h] + table[w][h]).astype(np.float32)
+    return flat.reshape(H, W, 3)
+
+
+@pytest.mark.parametrize("h,w,box", [(6, 9, 3), (9, 6, 3), (8, 8, 5), (5, 7, 1), (10, 4, 4)])
+def test_bloom_filter(orc, h, w, box):
+    rng = np.random.default_rng(h * 100 + w)
+    img = rng.random((h, w, 3)).astype(np.float32)
+    img[0, 0] = 0.5  # exactly at the threshold: not bright
+    got = srt.bloom(img, 0.5, box)
+    assert_bits_equal(got, orc.bloom(img, 0.5, box), "mirror vs oracle")
+    assert_bits_equal(got, _bloom_by_hand(img, 0.5, box), "mirror vs the filter spelled out")
+    if box > 1:
+        assert np.abs(got - img).max() > 0.1
