@@ -35,6 +35,10 @@ extern "C" {
 #define SRT_F_TEXTURE (1u << 5)
 #define SRT_F_ACCEL (1u << 6)
 #define SRT_F_MULTISAMPLE (1u << 7)
+/* extra.enableTransparency (reference src/render.cpp:111-120): a hit of a material with transparency < 1 also
+ * sends the ray on through the surface, so a sample's rays form a binary tree; the hits of its deepest level
+ * (max_depth) then contribute nothing, as in the reference. */
+#define SRT_F_TRANSPARENCY (1u << 10)
 /* Traversal policy.  0: the reference's exact visiting rule (a shadow ray walks the whole tree until its
  * first hit).  1: additionally skip every box whose slab test fails; same result up to rounding of
  * hit points, orders of magnitude less work.  The host mirror sets it by default. */

@@ -21,6 +21,7 @@ F_TEXTURE = 1 << 5
 F_ACCEL = 1 << 6
 F_MULTISAMPLE = 1 << 7
 F_SAH = 1 << 8
+F_TRANSPARENCY = 1 << 10
 F_MISS_CULL = 1 << 16
 
 LIGHT_STRIDE = 22

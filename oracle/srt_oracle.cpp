@@ -557,7 +557,7 @@ V3 light_contribution(Ctx& c, const Ray& ray, const HitInfo& hit, uint32_t path,
     return res;
 }
 
-/* getFinalColor, src/render.cpp:83-150 (transparency / environment map / debug branches left out) */
+/* getFinalColor, src/render.cpp:83-150 (environment map / debug branches left out) */
 V3 final_color(Ctx& c, Ray ray, int depth, uint32_t path, orc_hit* primary)
 {
     HitInfo hit;
@@ -582,6 +582,17 @@ V3 final_color(Ctx& c, Ray ray, int depth, uint32_t path, orc_hit* primary)
         V3 ks = hit.material.ks;
         if (!(ks == V3 { 0.0f, 0.0f, 0.0f }) && depth < c.max_depth)
             Lo = Lo + ks * final_color(c, refl, depth + 1, path, nullptr);
+    }
+    if (c.features & ORC_F_TRANSPARENCY) {
+        /* :111-120, :129-130.  Neither branch taken (depth cap reached, or transparency above 1): black. */
+        V3 finalColor = { 0, 0, 0 };
+        const float tr = hit.material.transparency;
+        Ray through = { ray.o + ray.d * (0.000001f + ray.t), ray.d, FLT_MAX };
+        if (depth < c.max_depth && tr < 1.0f)
+            finalColor = finalColor + (tr * Lo + (1 - tr) * final_color(c, through, depth + 1, path, nullptr));
+        else if (depth < c.max_depth && tr == 1.0f)
+            finalColor = finalColor + Lo;
+        return finalColor;
     }
     return Lo;
 }

@@ -26,6 +26,7 @@ enum {
     ORC_F_ACCEL          = 1u << 6,
     ORC_F_MULTISAMPLE    = 1u << 7,  /* extra.enableMultipleRaysPerPixel */
     ORC_F_SAH            = 1u << 8,  /* extra.enableBvhSahBinning (build only) */
+    ORC_F_TRANSPARENCY   = 1u << 10, /* extra.enableTransparency */
     /* traversal policy: 0 = reference-faithful, 1 = additionally cull every box whose slab test fails */
     ORC_F_MISS_CULL      = 1u << 16,
 };

@@ -30,6 +30,7 @@ F_TEXTURE = 1 << 5
 F_ACCEL = 1 << 6
 F_MULTISAMPLE = 1 << 7
 F_SAH = 1 << 8           # host-side build option (extra.enableBvhSahBinning)
+F_TRANSPARENCY = 1 << 10  # extra.enableTransparency
 F_BLOOM = 1 << 9         # host-side pass of the C++ mirror (extra.enableBloomEffect); not a kernel flag
 F_MISS_CULL = 1 << 16    # traversal policy; clear it for the reference's exact visiting rule
 

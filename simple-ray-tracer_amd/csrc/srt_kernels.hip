@@ -324,7 +324,7 @@ SRT_DI bool bvh_query(const SceneDev& sc, uint32_t features, f3 o, f3 d, float& 
 struct Surface {
     f3 normal, bary, kd, ks;
     f2 uv;
-    float shininess;
+    float shininess, transparency;
     uint32_t mesh, tri;
 };
 
@@ -361,6 +361,7 @@ SRT_DI void surface_at(const SceneDev& sc, uint32_t features, f3 o, f3 d, float 
     s.kd = mk3(m.kd[0], m.kd[1], m.kd[2]);
     s.ks = mk3(m.ks[0], m.ks[1], m.ks[2]);
     s.shininess = m.shininess;
+    s.transparency = m.transparency;
     const f3 p = o + d * T;
     const float4* at = sc.attrs + 4ull * pos;
     if (features & SRT_F_NORMAL_INTERP) {
@@ -948,8 +949,9 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
     const uint32_t stride = gridDim.x * SRT_BLOCK;
     for (uint32_t base = blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t h = base + (threadIdx.x & 63u);
-        bool spawn = false;
+        bool spawn = false, through = false;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), nthr = mk3(0, 0, 0);
+        f3 to = mk3(0, 0, 0), td = mk3(0, 0, 1), tthr = mk3(0, 0, 0);
         uint32_t sample = 0;
         if (h < n) {
             f3 o, d, thr;
@@ -960,23 +962,46 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             surface_at(sc, rp.features, o, d, T, tri, sf);
             nShaded += 1;
             const f3 Lo = light_contribution(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, vis, (unsigned long long)h * shadows_per_hit);
+            /* Share of this hit's own light in the sample.  With transparency (reference src/render.cpp:111-120) a
+             * hit at the depth cap, or of a material with transparency above 1, returns black; a material with
+             * transparency tr < 1 keeps tr of its light (and of its reflection) and passes 1 - tr on. */
+            const bool seeThrough = (rp.features & SRT_F_TRANSPARENCY) != 0;
+            const float tr = sf.transparency;
+            const bool black = seeThrough && !(depth < rp.max_depth && tr <= 1.0f);
+            const float keep = (seeThrough && tr < 1.0f) ? tr : 1.0f;
+            const f3 own = thr * keep;
             float* a3 = acc + 3ull * sample;
-            if (depth == 0) {
-                a3[0] = Lo.x, a3[1] = Lo.y, a3[2] = Lo.z;
-            } else {
-                a3[0] = a3[0] + thr.x * Lo.x;
-                a3[1] = a3[1] + thr.y * Lo.y;
-                a3[2] = a3[2] + thr.z * Lo.z;
+            if (!black) {
+                if (depth == 0) {
+                    a3[0] = keep * Lo.x, a3[1] = keep * Lo.y, a3[2] = keep * Lo.z;
+                } else if (seeThrough) {
+                    /* several rays of one sample can be at the same depth: their shares are added atomically
+                     * (the order of the additions, hence the last bits of the sum, may vary between runs) */
+                    atomicAdd(a3 + 0, own.x * Lo.x);
+                    atomicAdd(a3 + 1, own.y * Lo.y);
+                    atomicAdd(a3 + 2, own.z * Lo.z);
+                } else {
+                    a3[0] = a3[0] + thr.x * Lo.x;
+                    a3[1] = a3[1] + thr.y * Lo.y;
+                    a3[2] = a3[2] + thr.z * Lo.z;
+                }
             }
-            if ((rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f)) {
+            if (!black && (rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f)) {
                 /* computeReflectionRay, reference src/shading.cpp:33-51; offset = float(pow(10, -5)) */
                 const float offset = 9.99999975e-06f;
                 const f3 dn = normalize3(d);
                 const f3 nn = normalize3(sf.normal);
                 rd = dn - ((2.0f * dot3(dn, nn)) * nn);
                 ro = (o + d * T) + (offset * rd);
-                nthr = thr * sf.ks;
+                nthr = own * sf.ks;
                 spawn = true;
+            }
+            if (!black && seeThrough && tr < 1.0f) {
+                /* the ray continued behind the surface, reference src/render.cpp:113 */
+                to = o + d * (0.000001f + T);
+                td = d;
+                tthr = thr * (1 - tr);
+                through = true;
             }
         }
         const uint32_t q = queue_slot(spawn, next_count);
@@ -984,6 +1009,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             next_paths[3ull * q] = make_float4(ro.x, ro.y, ro.z, rd.x);
             next_paths[3ull * q + 1] = make_float4(rd.y, rd.z, nthr.x, nthr.y);
             next_paths[3ull * q + 2] = make_float4(nthr.z, __uint_as_float(sample), 0.0f, 0.0f);
+        }
+        if (rp.features & SRT_F_TRANSPARENCY) {
+            const uint32_t q2 = queue_slot(through, next_count);
+            if (through) {
+                next_paths[3ull * q2] = make_float4(to.x, to.y, to.z, td.x);
+                next_paths[3ull * q2 + 1] = make_float4(td.y, td.z, tthr.x, tthr.y);
+                next_paths[3ull * q2 + 2] = make_float4(tthr.z, __uint_as_float(sample), 0.0f, 0.0f);
+            }
         }
     }
     flush_counters(cnt, 0, 0, nShaded, st);
@@ -1527,7 +1560,8 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
     mark(d, st, 0, timing);
     hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0);
-    const int last_depth = (rp.features & SRT_F_RECURSIVE) ? rp.max_depth : 0;
+    const bool branching = (rp.features & SRT_F_TRANSPARENCY) != 0;
+    const int last_depth = (rp.features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY)) ? rp.max_depth : 0;
     for (int depth = 0; depth <= last_depth; ++depth) {
         const float4* cur = (const float4*)d->path[depth & 1].p;
         float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
@@ -1541,6 +1575,27 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
             acc, (const unsigned char*)vis, sph, d->counters + 2);
         if (depth == last_depth)
             break;
+        if (branching) {
+            /* A hit may send on two rays, so the queues can outgrow the sample count: read how many rays this
+             * depth spawned and make room for their hits, their visibility bytes and twice as many successors.
+             * Everything the buffers held is dead by now (hits, visibility and rays of this depth). */
+            uint32_t spawned = 0;
+            HIPCHK(hipMemcpyAsync(&spawned, path_count + depth + 1, sizeof spawned, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (spawned == 0)
+                break;
+            if (spawned >= (1u << 30))
+                return fail(SRT_ERR_INVALID, "transparency: %u rays at depth %d; render a smaller rectangle", spawned, depth + 1);
+            rc = d->hq_slot.reserve((size_t)spawned * 4);
+            if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)spawned * 4);
+            if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)spawned * 4);
+            if (rc == SRT_OK) rc = d->vis.reserve((size_t)spawned * sph + 64);
+            if (rc == SRT_OK) rc = d->path[depth & 1].reserve((size_t)spawned * 2 * 48);
+            if (rc != SRT_OK)
+                return rc;
+            hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
+            vis = (unsigned char*)d->vis.p;
+        }
         mark(d, st, 1, timing);
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
             path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1);
@@ -1593,9 +1648,11 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
     if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
-    if (rc == SRT_OK && (p->features & SRT_F_RECURSIVE)) {
-        rc = d->path[0].reserve((size_t)n * 48);
-        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * 48);
+    if (rc == SRT_OK && (p->features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
+        /* with transparency a hit may send on two rays */
+        const size_t per = (p->features & SRT_F_TRANSPARENCY) ? 96 : 48;
+        rc = d->path[0].reserve((size_t)n * per);
+        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
     }
     if (rc != SRT_OK)
         return rc;
@@ -1712,9 +1769,10 @@ int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int6
     if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
-    if (rc == SRT_OK && (features & SRT_F_RECURSIVE)) {
-        rc = d->path[0].reserve((size_t)n * 48);
-        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * 48);
+    if (rc == SRT_OK && (features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
+        const size_t per = (features & SRT_F_TRANSPARENCY) ? 96 : 48;
+        rc = d->path[0].reserve((size_t)n * per);
+        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
     }
     if (rc != SRT_OK)
         return rc;

@@ -58,6 +58,7 @@ int main(int argc, char** argv)
         }
         Features features = config.features;
         features.enableSoftShadow = config.backend.enableSoftShadow;
+        features.extra.enableTransparency = config.backend.enableTransparency;
         BvhInterface bvh { &scene, features };
 
         using clock = std::chrono::high_resolution_clock;

@@ -97,6 +97,7 @@ std::ostream& operator<<(std::ostream& os, const Config& config)
        << "    - gpu: " << b.gpu << std::endl
        << "    - num_rays: " << b.numRays << std::endl
        << "    - enable_soft_shadow: " << b.enableSoftShadow << std::endl
+       << "    - enable_transparency: " << b.enableTransparency << std::endl
        << "    - traversal: " << (b.referenceTraversal ? "reference" : "miss-cull") << std::endl
        << "    - max_depth: " << b.maxDepth << std::endl
        << "    - seed: " << b.seed << std::endl;
@@ -262,6 +263,7 @@ static Config fromTable(const toml::Value& table)
         b.maxDepth = (int)number(backend["max_depth"], 5.0f);
         b.seed = (uint32_t)number(backend["seed"], 0.0f);
         optionalBool(backend["enable_soft_shadow"], b.enableSoftShadow);
+        optionalBool(backend["enable_transparency"], b.enableTransparency);
         if (backend["traversal"].kind == toml::Value::String) {
             if (backend["traversal"].s == "reference")
                 b.referenceTraversal = true;

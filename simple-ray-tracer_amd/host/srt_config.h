@@ -26,6 +26,7 @@ struct BackendConfig {
     int gpu = 0;
     int numRays = 1;                 /* the reference's command-line path always renders with numRays = 1 (src/main.cpp:45,476) */
     bool enableSoftShadow = false;   /* the reference's reader never sets Features::enableSoftShadow */
+    bool enableTransparency = false; /* nor extra.enableTransparency (only its viewer's check box does) */
     bool referenceTraversal = false; /* "traversal" = "reference" | "miss-cull" */
     int maxDepth = 5;
     uint32_t seed = 0;

@@ -65,6 +65,7 @@ uint32_t featureMask(const Features& f, bool referenceTraversal)
     if (f.enableTextureMapping) m |= SRT_F_TEXTURE;
     if (f.enableAccelStructure) m |= SRT_F_ACCEL;
     if (f.extra.enableMultipleRaysPerPixel) m |= SRT_F_MULTISAMPLE;
+    if (f.extra.enableTransparency) m |= SRT_F_TRANSPARENCY;
     if (!referenceTraversal) m |= SRT_F_MISS_CULL;
     return m;
 }
@@ -593,8 +594,7 @@ Ray Trackball::generateRay(const vec2& pixel) const
 static void rejectUnsupported(const Features& f)
 {
     const char* what = nullptr;
-    if (f.extra.enableTransparency) what = "transparency";
-    else if (f.extra.enableEnvironmentMapping) what = "environment mapping";
+    if (f.extra.enableEnvironmentMapping) what = "environment mapping";
     else if (f.extra.enableMotionBlur) what = "motion blur";
     else if (f.extra.enableDepthOfField) what = "depth of field";
     if (what)

@@ -42,6 +42,7 @@ static Features featuresFromMask(uint32_t m)
     f.extra.enableMultipleRaysPerPixel = m & SRT_F_MULTISAMPLE;
     f.extra.enableBvhSahBinning = m & SRTH_F_SAH;
     f.extra.enableBloomEffect = m & SRTH_F_BLOOM;
+    f.extra.enableTransparency = m & SRT_F_TRANSPARENCY;
     return f;
 }
 

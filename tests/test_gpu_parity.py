@@ -410,6 +410,61 @@ def test_dragon_8k_64spp_window(orc, dragon_pair):
     assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
 
 
+def _see_through_cornell(orc, scenes):
+    """Cornell box (mirror included) with materials made partly transparent: reflection and transmission together,
+    so a sample's rays form a binary tree."""
+    d = dict(scenes("cornell"))
+    m = d["materials"].copy()
+    m[:, 7] = np.resize(np.array([0.3, 1.0, 0.7, 0.55], np.float32), len(m))
+    d["materials"] = m
+    return orc.Bvh(d, orc.F_ACCEL), srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+
+
+@pytest.mark.parametrize("policy", ["reference", "cull"])
+@pytest.mark.parametrize("max_depth", [5, 2, 0])
+def test_transparency_with_reflection(orc, scenes, gpu, max_depth, policy):
+    ob, gb = _see_through_cornell(orc, scenes)
+    feat = FEATURE_SETS["recursive"] | srt.F_TRANSPARENCY | (srt.F_MISS_CULL if policy == "cull" else 0)
+    want = ob.render(orc.make_camera(96, 72), feat, max_depth=max_depth)
+    got = gb.render(srt.make_camera(96, 72), feat, max_depth=max_depth)
+    assert np.array_equal(got["tri"], want["tri"])
+    assert np.abs(got["rgb"] - want["rgb"]).max() <= RGB_TOL
+    wc, gc = want["counters"], got["counters"]
+    assert (gc["path_rays"], gc["shadow_rays"], gc["shaded_hits"]) == (wc["path_rays"], wc["shadow_rays"], wc["shaded_hits"])
+    if max_depth == 0:
+        assert not got["rgb"].any()  # every hit sits at the depth cap: black, as in the reference
+    else:
+        assert want["rgb"].max() > 0.05 and gc["path_rays"] > 96 * 72 + 1000
+
+
+def test_transparency_cube_scene(orc, pair):
+    # the prebuilt cube is the one reference scene whose materials are transparent (d 0.452632); its light is a
+    # segment light, hence soft shadows
+    ob, gb = pair("cube")
+    for extra in (0, srt.F_RECURSIVE):
+        feat = SH | srt.F_SOFT_SHADOW | srt.F_TRANSPARENCY | srt.F_MISS_CULL | extra
+        want = ob.render(orc.make_camera(64, 48), feat, seed=3)
+        got = gb.render(srt.make_camera(64, 48), feat, seed=3)
+        _compare_frames(got, want, "transparent cube")
+        assert got["counters"]["path_rays"] == want["counters"]["path_rays"] > 64 * 48
+    # the C++ mirror: Features::extra.enableTransparency
+    rgb = srt.mirror_render(gb, SH | srt.F_SOFT_SHADOW | srt.F_TRANSPARENCY | srt.F_MISS_CULL, 64, 48)
+    want = ob.render(orc.make_camera(64, 48), SH | srt.F_SOFT_SHADOW | srt.F_TRANSPARENCY | srt.F_MISS_CULL)
+    assert np.abs(rgb - want["rgb"]).max() <= RGB_TOL
+    # plain opaque rendering of the same scene differs: the flag does something
+    opaque = gb.render(srt.make_camera(64, 48), SH | srt.F_SOFT_SHADOW | srt.F_MISS_CULL)
+    assert np.abs(opaque["rgb"] - want["rgb"]).max() > 0.05
+
+
+def test_transparency_final_color_batch(orc, scenes, gpu):
+    ob, gb = _see_through_cornell(orc, scenes)
+    rays = _rays_for(orc, scenes("cornell"), 2000, 5)
+    feat = FEATURE_SETS["recursive"] | srt.F_TRANSPARENCY | srt.F_MISS_CULL
+    want, _ = ob.final_color(rays, feat)
+    got = gb.final_color(rays, feat)
+    assert np.abs(got - want).max() <= RGB_TOL and want.max() > 0.05
+
+
 def test_bloom_through_the_mirror(orc, pair):
     """renderRayTracing with extra.enableBloomEffect and the parameters the reference's callers pass (threshold 0.5,
     boxSize 1 -> a 3-box): the frame, then Screen::applyBloomFilter on it."""
