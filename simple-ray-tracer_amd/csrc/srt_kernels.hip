@@ -5,19 +5,21 @@
  *
  *   trace_primary   one lane per pixel sample: camera ray (Trackball::generateRay) + BVH query; lanes that
  *                   hit are compacted (wave ballot + one atomic per wave) into the hit queue
- *   trace_shadow    one lane per (queued hit, light sample): the shadow-ray BVH query of that sample, by the same
- *                   traversal routine; one visibility bit per pair
+ *   trace_shadow    one lane per (queued hit, light sample): the shadow-ray BVH query of that sample (a walk of its
+ *                   own, with idle lanes refilled from the queue); one visibility byte per pair
  *   shade           one lane per queued hit: hit attributes, light loop (Phong term of every sample times its
- *                   visibility bit, summed in the reference's order) into the sample's accumulator slot,
- *                   reflection ray compacted into the next path queue
+ *                   visibility byte, summed in the reference's order) into the sample's accumulator slot,
+ *                   reflection ray (and, with transparency, the ray continued behind the surface) compacted
+ *                   into the next path queue
  *   trace_secondary one lane per queued path ray: BVH query, hits compacted into the hit queue
  *   ... trace_shadow / shade / trace_secondary repeat up to max_depth times ...
  *   resolve         one lane per pixel: sum of the pixel's samples in the reference's loop order, division,
  *                   store at Screen::setPixel's position
  *
  * Queue kernels run as a persistent grid that strides over the queue; the queue length is read from
- * device memory.  A sample owns its accumulator slot, so no floating-point atomics are used and a frame
- * is bit-reproducible run to run.
+ * device memory.  A sample owns its accumulator slot and has at most one ray per depth, so no floating-point
+ * atomics are used and a frame is bit-reproducible run to run (the exception is SRT_F_TRANSPARENCY, where a
+ * sample's rays branch and their shares are added atomically).
  *
  * Traversal (BoundingVolumeHierarchy::intersect, reference src/bounding_volume_hierarchy.cpp:316-393).
  * The reference keeps a LIFO of node indices, tests a child's box against the running closest distance C
@@ -145,9 +147,8 @@ SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& 
  * (triangle tests).  Each trip the wave votes (ballot) and runs only the kind of step more of its lanes are
  * waiting for (weighted by cost); the others keep their node for a later trip.  A wave therefore never pays for
  * both kinds of work in one trip.  Which lane advances when does not change any
- * lane's own visiting order.  FAST selects div_by for the slab divisions.  ANYHIT is for shadow queries: their
- * caller only asks "accepted something and final t < 0.99"; t never grows, so the first accepted hit below
- * 0.99 settles the answer and the walk stops there. */
+ * lane's own visiting order.  FAST selects div_by for the slab divisions.  (Shadow queries, whose caller only
+ * asks "accepted something and final t < 0.99", have a walk of their own further down: swalk_*.) */
 /* One BVH query in flight on a lane. */
 struct Walk {
     f3 o, d;
@@ -226,7 +227,7 @@ SRT_DI void walk_inner(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
 }
 
 /* Visit of the leaf the lane stands on: its triangles in stored order (reference :359-368). */
-template <bool COUNT, bool ANYHIT>
+template <bool COUNT>
 SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
 {
     const uint32_t first = w.cur & 0x00FFFFFFu;
@@ -239,10 +240,7 @@ SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
             w.hitTri = first + k;
         }
     }
-    if (ANYHIT && w.T < 0.99f && w.C != SRT_FLT_MAX)
-        w.alive = false;
-    else
-        w.alive = walk_pop(w, stk);
+    w.alive = walk_pop(w, stk);
 }
 
 /* Vote weights: a leaf step costs about 2.5 box steps, so it is worth taking once half as many lanes wait for it
@@ -260,7 +258,7 @@ SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
 
 /* One trip of the wave: vote, then the kind of step more live lanes are waiting for.  Returns false when no
  * lane of the wave has a query in flight. */
-template <bool CULL, bool COUNT, bool FAST, bool ANYHIT>
+template <bool CULL, bool COUNT, bool FAST>
 SRT_DI bool walk_trip(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
 {
     const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
@@ -277,17 +275,17 @@ SRT_DI bool walk_trip(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
         if (COUNT && (int)(threadIdx.x & 63u) == __ffsll((long long)mLeaf) - 1)
             st.wave_leaf += 1;
         if (atLeaf)
-            walk_leaf<COUNT, ANYHIT>(sc, w, stk, st);
+            walk_leaf<COUNT>(sc, w, stk, st);
     }
     return true;
 }
 
-template <bool CULL, bool COUNT, bool FAST, bool ANYHIT>
+template <bool CULL, bool COUNT, bool FAST>
 SRT_DI bool traverse_loop(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     Walk w;
     walk_begin<CULL, COUNT, FAST>(sc, w, o, d, T, st);
-    while (walk_trip<CULL, COUNT, FAST, ANYHIT>(sc, w, stk, st)) {
+    while (walk_trip<CULL, COUNT, FAST>(sc, w, stk, st)) {
     }
     T = w.T;
     hitTri = w.hitTri;
@@ -301,21 +299,21 @@ SRT_DI bool ray_in_fast_range(const SceneDev& sc, f3 o, f3 d)
         && coord_in_fast_range(o.y) && coord_in_fast_range(o.z);
 }
 
-template <bool CULL, bool COUNT, bool ANYHIT>
+template <bool CULL, bool COUNT>
 SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     /* one decision per wave: every lane's operands in the ranges div_by is exact for, or plain division for all */
     if (__all(ray_in_fast_range(sc, o, d)))
-        return traverse_loop<CULL, COUNT, true, ANYHIT>(sc, o, d, T, hitTri, stk, st);
-    return traverse_loop<CULL, COUNT, false, ANYHIT>(sc, o, d, T, hitTri, stk, st);
+        return traverse_loop<CULL, COUNT, true>(sc, o, d, T, hitTri, stk, st);
+    return traverse_loop<CULL, COUNT, false>(sc, o, d, T, hitTri, stk, st);
 }
 
-template <bool CULL, bool COUNT, bool ANYHIT = false>
+template <bool CULL, bool COUNT>
 SRT_DI bool bvh_query(const SceneDev& sc, uint32_t features, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     hitTri = 0xFFFFFFFFu;
     if (features & SRT_F_ACCEL)
-        return traverse<CULL, COUNT, ANYHIT>(sc, o, d, T, hitTri, stk, st);
+        return traverse<CULL, COUNT>(sc, o, d, T, hitTri, stk, st);
     return traverse_linear<COUNT>(sc, o, d, T, hitTri, st);
 }
 
