@@ -410,6 +410,25 @@ def test_dragon_8k_64spp_window(orc, dragon_pair):
     assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
 
 
+@pytest.mark.parametrize("name", ["monkey", "teapot"])
+def test_sah_binned_tree(orc, scenes, gpu, name):
+    """extra.enableBvhSahBinning (reference src/bounding_volume_hierarchy.cpp:96-178): a different tree, same
+    traversal; queries and a frame against the oracle built the same way."""
+    d = scenes(name)
+    ob, gb = orc.Bvh(d, orc.F_ACCEL | orc.F_SAH), srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL | srt.F_SAH)
+    assert (gb.num_levels, gb.num_leaves) == (ob.num_levels, ob.num_leaves)
+    plain = orc.Bvh(d, orc.F_ACCEL)
+    assert (ob.num_levels, ob.num_nodes) != (plain.num_levels, plain.num_nodes) or name == "monkey"
+    rays = _rays_for(orc, d, 3000, 9)
+    for feat in (orc.F_ACCEL, orc.F_ACCEL | orc.F_MISS_CULL):
+        want, _ = ob.intersect(rays, feat)
+        got, _, _ = gb.intersect(rays, feat)
+        assert np.array_equal(got["hit"], want["hit"]) and np.array_equal(got["tri"], want["tri"])
+        assert_bits_equal(got["t"], want["t"], "t")
+    feat = FEATURE_SETS["recursive"] | srt.F_MISS_CULL
+    _compare_frames(gb.render(srt.make_camera(96, 64), feat), ob.render(orc.make_camera(96, 64), feat), f"{name} SAH tree")
+
+
 def _see_through_cornell(orc, scenes):
     """Cornell box (mirror included) with materials made partly transparent: reflection and transmission together,
     so a sample's rays form a binary tree."""
