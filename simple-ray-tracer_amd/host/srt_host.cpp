@@ -81,15 +81,15 @@ static vec3 getMedian(const TriangleOrNode& t, const Scene& scene)
     return ((p1 + p2) + p3) / 3.0f;
 }
 
-/* getBox, reference :47-68 */
-static AxisAlignedBox getBox(std::vector<TriangleOrNode>::const_iterator begin, std::vector<TriangleOrNode>::const_iterator end, const Scene& scene)
+/* getBox, reference :47-68, over triangles[begin, end) with the corners taken from the per-triangle table (the
+ * same values folded in the same order) */
+AxisAlignedBox BoundingVolumeHierarchy::getBox(const std::vector<TriangleOrNode>& triangles, size_t begin, size_t end) const
 {
     vec3 lower = { FLT_MAX, FLT_MAX, FLT_MAX };
     vec3 upper = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-    for (auto it = begin; it != end; ++it) {
-        const Mesh& mesh = scene.meshes[it->meshIndex];
-        const uvec3& tr = mesh.triangles[it->triangleIndex];
-        const vec3 &v1 = mesh.vertices[tr.x].position, &v2 = mesh.vertices[tr.y].position, &v3 = mesh.vertices[tr.z].position;
+    for (size_t k = begin; k < end; ++k) {
+        const vec3* c = &m_corners[3 * globalIndex(triangles[k])];
+        const vec3 &v1 = c[0], &v2 = c[1], &v3 = c[2];
         upper.x = std::max(std::max(upper.x, v1.x), std::max(v2.x, v3.x));
         upper.y = std::max(std::max(upper.y, v1.y), std::max(v2.y, v3.y));
         upper.z = std::max(std::max(upper.z, v1.z), std::max(v2.z, v3.z));
@@ -104,41 +104,101 @@ BoundingVolumeHierarchy::BoundingVolumeHierarchy(Scene* pScene, const Features& 
     : m_pScene(pScene)
 {
     std::vector<TriangleOrNode> triangles;
-    for (size_t i = 0; i < pScene->meshes.size(); ++i)
+    for (size_t i = 0; i < pScene->meshes.size(); ++i) {
+        m_meshOffset.push_back(triangles.size());
         for (size_t j = 0; j < pScene->meshes[i].triangles.size(); ++j)
             triangles.push_back(TriangleOrNode { i, j, 0 });
-    if (features.extra.enableBvhSahBinning)
-        sahConstructorHelper(triangles, 0, triangles.size(), 0, 0);
-    else
-        constructorHelper(triangles, 0, triangles.size(), 0, 0);
-    for (const Node& node : nodes)
+    }
+    m_centroid.resize(triangles.size());
+    m_corners.resize(3 * triangles.size());
+    for (size_t k = 0; k < triangles.size(); ++k) {
+        const Mesh& mesh = pScene->meshes[triangles[k].meshIndex];
+        const uvec3& tr = mesh.triangles[triangles[k].triangleIndex];
+        m_centroid[k] = getMedian(triangles[k], *pScene);
+        m_corners[3 * k] = mesh.vertices[tr.x].position, m_corners[3 * k + 1] = mesh.vertices[tr.y].position, m_corners[3 * k + 2] = mesh.vertices[tr.z].position;
+    }
+    /* Subtrees are independent once their triangle range is fixed, so the top levels fork; every node is built by
+     * the reference's own steps and numbered as its recursion numbers it, whatever the number of threads. */
+    const int forkLevels = triangles.size() >= 4096 ? 5 : 0;
+#pragma omp parallel if (forkLevels > 0)
+#pragma omp single
+    {
+        if (features.extra.enableBvhSahBinning)
+            sahConstructorHelper(nodes, triangles, 0, triangles.size(), 0, 0, forkLevels);
+        else
+            constructorHelper(nodes, triangles, 0, triangles.size(), 0, 0, forkLevels);
+    }
+    for (const Node& node : nodes) {
         m_numLevels = std::max(m_numLevels, node.level + 1);
+        m_numLeaves += node.isLeaf ? 1 : 0;
+    }
+    m_centroid = {};
+    m_corners = {};
 }
 
-static void sortByCentroid(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, const Scene& scene)
+/* std::sort, not std::stable_sort: equal centroids end up in libstdc++ introsort order, as in the reference (:81-85).
+ * The sort runs on (centroid coordinate, position) pairs: introsort's moves depend only on the outcomes of the
+ * comparisons, which are those of the reference's comparator, so the permutation is the one sorting the
+ * triangle list itself produces. */
+void BoundingVolumeHierarchy::sortByCentroid(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis) const
 {
-    /* std::sort, not std::stable_sort: equal centroids end up in libstdc++ introsort order, as in the reference (:81-85) */
-    std::sort(triangles.begin() + left, triangles.begin() + right, [&scene, whichAxis](const TriangleOrNode& a, const TriangleOrNode& b) {
-        return getMedian(a, scene)[whichAxis] < getMedian(b, scene)[whichAxis];
-    });
+    struct Key {
+        float value;
+        uint32_t from;
+    };
+    std::vector<Key> keys(right - left);
+    for (size_t k = 0; k < keys.size(); ++k)
+        keys[k] = { m_centroid[globalIndex(triangles[left + k])][whichAxis], (uint32_t)k };
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.value < b.value; });
+    std::vector<TriangleOrNode> sorted(keys.size());
+    for (size_t k = 0; k < keys.size(); ++k)
+        sorted[k] = triangles[left + keys[k].from];
+    std::copy(sorted.begin(), sorted.end(), triangles.begin() + left);
+}
+
+/* Appends two finished subtrees and their parent to out; child indices become positions in out. */
+size_t BoundingVolumeHierarchy::splice(std::vector<Node>& out, std::vector<Node>& left, std::vector<Node>& right, Node&& parent) const
+{
+    for (std::vector<Node>* part : { &left, &right }) {
+        const size_t base = out.size();
+        for (Node& n : *part) {
+            if (!n.isLeaf)
+                n.triangles[0].nodeIndex += base, n.triangles[1].nodeIndex += base;
+            out.push_back(std::move(n));
+        }
+    }
+    parent.triangles[0].nodeIndex = out.size() - right.size() - 1;
+    parent.triangles[1].nodeIndex = out.size() - 1;
+    out.push_back(std::move(parent));
+    return out.size() - 1;
 }
 
 /* constructorHelper, reference :70-94: median split on the centroid, axis cycling with depth, one-triangle
  * leaves, depth cap 17 levels, children appended before their parent */
-size_t BoundingVolumeHierarchy::constructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level)
+size_t BoundingVolumeHierarchy::constructorHelper(std::vector<Node>& out, std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis,
+                                                  int level, int forkLevels)
 {
     const auto beginIt = triangles.begin() + left, endIt = triangles.begin() + right;
     if (right - left <= 1 || level > 16) {
-        nodes.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(beginIt, endIt, *m_pScene) });
-        m_numLeaves += 1;
-        return nodes.size() - 1;
+        out.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(triangles, left, right) });
+        return out.size() - 1;
     }
-    sortByCentroid(triangles, left, right, whichAxis, *m_pScene);
+    sortByCentroid(triangles, left, right, whichAxis);
     const size_t median = (left + right + 1) / 2;
-    const size_t leftIndex = constructorHelper(triangles, left, median, (whichAxis + 1) % 3, level + 1);
-    const size_t rightIndex = constructorHelper(triangles, median, right, (whichAxis + 1) % 3, level + 1);
-    nodes.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, getBox(beginIt, endIt, *m_pScene) });
-    return nodes.size() - 1;
+    if (forkLevels > 0) {
+        std::vector<Node> l, r;
+#pragma omp task shared(l, triangles)
+        constructorHelper(l, triangles, left, median, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
+#pragma omp task shared(r, triangles)
+        constructorHelper(r, triangles, median, right, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
+        const AxisAlignedBox box = getBox(triangles, left, right);
+#pragma omp taskwait
+        return splice(out, l, r, { false, level, { { 0, 0, 0 }, { 0, 0, 0 } }, box });
+    }
+    const size_t leftIndex = constructorHelper(out, triangles, left, median, (whichAxis + 1) % 3, level + 1, 0);
+    const size_t rightIndex = constructorHelper(out, triangles, median, right, (whichAxis + 1) % 3, level + 1, 0);
+    out.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, getBox(triangles, left, right) });
+    return out.size() - 1;
 }
 
 /* getProb, reference :96-113 */
@@ -154,38 +214,47 @@ static float getProb(const AxisAlignedBox& inner, const AxisAlignedBox& outer)
 }
 
 /* sahConstructorHelper with calculateCostOfDivision, reference :116-178 (five candidate planes) */
-size_t BoundingVolumeHierarchy::sahConstructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level)
+size_t BoundingVolumeHierarchy::sahConstructorHelper(std::vector<Node>& out, std::vector<TriangleOrNode>& triangles, size_t left, size_t right,
+                                                     int whichAxis, int level, int forkLevels)
 {
     const auto beginIt = triangles.begin() + left, endIt = triangles.begin() + right;
     if (right - left <= 1 || level > 16) {
-        nodes.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(beginIt, endIt, *m_pScene) });
-        m_numLeaves += 1;
-        return nodes.size() - 1;
+        out.push_back({ true, level, std::vector<TriangleOrNode>(beginIt, endIt), getBox(triangles, left, right) });
+        return out.size() - 1;
     }
-    sortByCentroid(triangles, left, right, whichAxis, *m_pScene);
-    const Scene& scene = *m_pScene;
+    sortByCentroid(triangles, left, right, whichAxis);
     const size_t planesNumber = std::min(static_cast<size_t>(5), right - left - 1);
-    const float leftBoundary = getMedian(*beginIt, scene)[whichAxis];
-    const float rightBoundary = getMedian(*(endIt - 1), scene)[whichAxis];
+    const float leftBoundary = m_centroid[globalIndex(triangles[left])][whichAxis];
+    const float rightBoundary = m_centroid[globalIndex(triangles[right - 1])][whichAxis];
     const float step = (rightBoundary - leftBoundary) / (planesNumber + 1);
     float minCost = FLT_MAX;
     size_t median = left;
+    const AxisAlignedBox outerBox = getBox(triangles, left, right);
     for (size_t i = 1; i <= planesNumber; ++i) {
         const float boundary = leftBoundary + step * i;
-        auto middle = beginIt;
-        while (middle != endIt && getMedian(*middle, scene)[whichAxis] < boundary)
+        size_t middle = left;
+        while (middle != right && m_centroid[globalIndex(triangles[middle])][whichAxis] < boundary)
             ++middle;
-        const AxisAlignedBox outerBox = getBox(beginIt, endIt, scene), leftBox = getBox(beginIt, middle, scene), rightBox = getBox(middle, endIt, scene);
-        const float cost = getProb(leftBox, outerBox) * (middle - beginIt) + getProb(rightBox, outerBox) * (endIt - middle);
+        const AxisAlignedBox leftBox = getBox(triangles, left, middle), rightBox = getBox(triangles, middle, right);
+        const float cost = getProb(leftBox, outerBox) * (middle - left) + getProb(rightBox, outerBox) * (right - middle);
         if (cost < minCost) {
             minCost = cost;
-            median = middle - triangles.begin();
+            median = middle;
         }
     }
-    const size_t leftIndex = sahConstructorHelper(triangles, left, median, (whichAxis + 1) % 3, level + 1);
-    const size_t rightIndex = sahConstructorHelper(triangles, median, right, (whichAxis + 1) % 3, level + 1);
-    nodes.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, getBox(beginIt, endIt, *m_pScene) });
-    return nodes.size() - 1;
+    if (forkLevels > 0) {
+        std::vector<Node> l, r;
+#pragma omp task shared(l, triangles)
+        sahConstructorHelper(l, triangles, left, median, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
+#pragma omp task shared(r, triangles)
+        sahConstructorHelper(r, triangles, median, right, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
+#pragma omp taskwait
+        return splice(out, l, r, { false, level, { { 0, 0, 0 }, { 0, 0, 0 } }, outerBox });
+    }
+    const size_t leftIndex = sahConstructorHelper(out, triangles, left, median, (whichAxis + 1) % 3, level + 1, 0);
+    const size_t rightIndex = sahConstructorHelper(out, triangles, median, right, (whichAxis + 1) % 3, level + 1, 0);
+    out.push_back({ false, level, { { 0, 0, leftIndex }, { 0, 0, rightIndex } }, outerBox });
+    return out.size() - 1;
 }
 
 /* ------------------------------------------------------------------------------------------ flatten */

@@ -232,8 +232,10 @@ struct FlatScene {
 class BoundingVolumeHierarchy {
 public:
     BoundingVolumeHierarchy(Scene* pScene, const Features& features);
-    size_t constructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level);
-    size_t sahConstructorHelper(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level);
+    /* The reference's two recursive builders.  `out` receives the subtree's nodes in post-order (indices local to
+     * out); the top `forkLevels` levels build their two subtrees as parallel tasks and splice them together. */
+    size_t constructorHelper(std::vector<Node>& out, std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level, int forkLevels);
+    size_t sahConstructorHelper(std::vector<Node>& out, std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis, int level, int forkLevels);
     [[nodiscard]] int numLevels() const { return m_numLevels; }
     [[nodiscard]] int numLeaves() const { return m_numLeaves; }
     const std::vector<Node>& nodeTable() const { return nodes; } /* post-order, root last, as in the reference */
@@ -245,6 +247,14 @@ private:
     int m_numLeaves = 0;
     Scene* m_pScene;
     std::vector<Node> nodes;
+    /* per triangle, in scene order (mesh after mesh): centroid and corner positions, computed once */
+    std::vector<size_t> m_meshOffset;
+    std::vector<vec3> m_centroid;
+    std::vector<vec3> m_corners;
+    [[nodiscard]] size_t globalIndex(const TriangleOrNode& t) const { return m_meshOffset[t.meshIndex] + t.triangleIndex; }
+    void sortByCentroid(std::vector<TriangleOrNode>& triangles, size_t left, size_t right, int whichAxis) const;
+    [[nodiscard]] AxisAlignedBox getBox(const std::vector<TriangleOrNode>& triangles, size_t begin, size_t end) const;
+    size_t splice(std::vector<Node>& out, std::vector<Node>& left, std::vector<Node>& right, Node&& parent) const;
 };
 
 class BvhInterface {
