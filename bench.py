@@ -104,7 +104,7 @@ def cpu_baseline(d, cfg, seconds, threads):
                       f"reference visiting rule (no miss culling), {threads} threads"}
 
 
-PROFILE_SUMMARY = "profiles/r01c_stack4_summary.txt"
+PROFILE_SUMMARY = "profiles/r01d_dynamic_summary.txt"
 PROFILE_KERNELS = {"trace_shadow": "void k_trace_shadow<true, false>", "trace_primary": "void k_trace_primary<true, false>"}
 
 
