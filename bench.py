@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--lanes", type=int, default=2, help="back-end contexts (each with its stream) a tiled frame alternates between")
     args = ap.parse_args()
 
     import torch
@@ -197,22 +198,41 @@ def main():
             counter = srt.TileCounter(name, False)
     tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter)
     n_tiles = tiler.n_tiles
-    stream = torch.cuda.current_stream()
+    # A frame cut into tiles alternates between two back-end contexts on two streams, so that the tail of one
+    # tile's kernels overlaps the start of the next tile's (a context owns its work buffers and scene copy).
+    lanes = [(bvh, torch.cuda.current_stream())]
+    if n_tiles > 1:
+        for ctx in range(1, max(1, args.lanes)):
+            srt.set_device(local_rank, context=ctx)
+            lanes.append((srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL), torch.cuda.Stream()))
+        srt.set_device(local_rank, context=0)
+
+    def lane():
+        return lanes[tiler.current % len(lanes)]
 
     def stream_fence():
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record(stream)
+        ev.record(lane()[1])
         return ev
 
     def one_step(flags):
-        """One frame: this rank's share of the tiles (enqueued on the current stream, written straight into the
+        """One frame: this rank's share of the tiles (enqueued on the lanes' streams, written straight into the
         rank's tile buffer in HBM), then the gather to rank 0."""
         def render_tile(rect, slot):
-            p = bvh.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rect, flags)
-            bvh.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], stream.cuda_stream)
+            b, stream = lane()
+            p = b.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rect, flags)
+            b.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], stream.cuda_stream)
 
-        k = tiler.render(render_tile, stream_fence if world > 1 else None)
-        tiler.gather(k)
+        t_a = time.perf_counter()
+        k = tiler.render(render_tile, stream_fence if n_tiles > 1 else None)
+        if os.environ.get("SRT_BENCH_DEBUG"):
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            tiler.gather(k)
+            torch.cuda.synchronize()
+            print(f"[rank {rank}] tiles {k} render {1e3 * (t_b - t_a):.1f} ms gather {1e3 * (time.perf_counter() - t_b):.1f} ms", file=sys.stderr, flush=True)
+        else:
+            tiler.gather(k)
         return k
 
     def fence():
@@ -221,31 +241,53 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def summed(parts):
+        """Element-wise sum of the lanes' counter dictionaries (one level of nesting allowed)."""
+        out = {}
+        for part in parts:
+            for key, val in part.items():
+                if isinstance(val, dict):
+                    out.setdefault(key, {})
+                    for k2, v2 in val.items():
+                        out[key][k2] = out[key].get(k2, 0) + v2
+                else:
+                    out[key] = out.get(key, 0) + val
+        return out
+
+    def read_counters():
+        return summed([b.read_counters(reset=True) for b, _ in lanes])
+
+    def kernel_times():
+        return summed([b.kernel_times(reset=True) for b, _ in lanes])
+
+    def read_kernel_counters():
+        return summed([b.read_kernel_counters(reset=True) for b, _ in lanes])
+
     for _ in range(args.warmup):
         one_step(0)
     fence()
-    bvh.read_counters(reset=True)
-    bvh.kernel_times(reset=True)
+    read_counters()
+    kernel_times()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(srt.RENDER_TIMING)
     fence()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    c = bvh.read_counters(reset=True)
+    c = read_counters()
     rays = torch.tensor([c["path_rays"] + c["shadow_rays"]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
     rays_per_frame = float(rays.item()) / args.steps
-    times = bvh.kernel_times(reset=True)
+    times = kernel_times()
 
     # algorithmic work of each kernel family, from one more (untimed) frame with the counting kernels
-    bvh.read_kernel_counters(reset=True)
+    read_kernel_counters()
     one_step(srt.RENDER_STATS)
     fence()
-    fam = bvh.read_kernel_counters(reset=True)
+    fam = read_kernel_counters()
 
     if rank == 0:
         dominant = max(times, key=lambda n: times[n]["ms"])
@@ -267,6 +309,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches_timed": launches_timed,
+                         "concurrent_lanes": len(lanes),  # > 1: launches of different tiles overlap, so do their timed intervals
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times},
                          "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]}},

@@ -145,6 +145,7 @@ def host():
     L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
     L.srth_write_bmp.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int]
     L.srth_set_device.argtypes = [C.c_int]
+    L.srth_set_device_context.argtypes = [C.c_int, C.c_int]
     L.srth_selftest_division.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     L.srth_mirror_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _f32p]
     L.srth_mirror_intersect_one.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
@@ -172,9 +173,10 @@ def _p(a, t=_f32p):
     return a.ctypes.data_as(t)
 
 
-def set_device(gpu):
-    """Select (and initialise) the GPU used by objects created afterwards on this thread."""
-    _check(host().srth_set_device(int(gpu)))
+def set_device(gpu, context=0):
+    """Select (and initialise) the GPU used by objects created afterwards on this thread.  Objects of different
+    contexts have independent back-end handles on the GPU, so their renders may overlap on different streams."""
+    _check(host().srth_set_device_context(int(gpu), int(context)))
 
 
 class Scene:

@@ -19,6 +19,8 @@ The reference does this with OpenMP `schedule(guided)` over image rows inside on
 (reference src/render.cpp:184-187).
 """
 import math
+import os
+import sys
 import time
 
 import torch
@@ -52,11 +54,13 @@ class FrameTiler:
                                                                            (self.rects[i][1] + self.rects[i][3]) / 2.0 - cy), i))
         self.cost_us = torch.zeros((self.n_tiles,), dtype=torch.int32)  # of this rank's tiles, by slot
         self._marks = []
+        self.current = 0  # ordinal of the tile being rendered: callbacks may use it to alternate between streams
 
     def render(self, render_tile, fence=None):
         """Draws tiles until this frame's counter runs out.  render_tile(rect, slot_tensor) renders (or
         enqueues) one tile into slot_tensor, laid out top row first; fence() returns an event-like object
-        (.synchronize(), .elapsed_time(later)) recorded after the work enqueued so far, None when render_tile is
+        (.synchronize(), .elapsed_time(later)) recorded after the work enqueued so far for the tile self.current
+        (callbacks that alternate between streams record on that tile's stream), None when render_tile is
         synchronous.  At most max_in_flight tiles are outstanding per rank, so a rank cannot hoard tiles it has
         not started."""
         k = 0
@@ -69,6 +73,7 @@ class FrameTiler:
             t = self.order[pos]
             if fence is not None and len(pending) >= self.max_in_flight:
                 pending.pop(0).synchronize()
+            self.current = k
             begin = fence() if fence is not None else time.perf_counter()
             render_tile(self.rects[t], self.tiles[k])
             end = fence() if fence is not None else time.perf_counter()
@@ -104,6 +109,8 @@ class FrameTiler:
 
     def gather(self, k):
         """Finished tiles of every rank into rank 0's frame (Screen layout: top row first)."""
+        t0 = time.perf_counter()
+        self._measure(k)  # also waits for this rank's tiles, whatever streams they were rendered on
         if self.world == 1:
             if self.n_tiles == 1 and (self.tw, self.th) == (self.W, self.H):
                 self.frame.copy_(self.tiles[0])
@@ -111,7 +118,6 @@ class FrameTiler:
                 self._place(self.ids[:k].tolist(), self.tiles)
             self.step += 1
             return
-        self._measure(k)
         n = self.n_tiles
         meta = torch.full((2 * n + 1,), -1, dtype=torch.int32)
         meta[0] = k
@@ -119,8 +125,10 @@ class FrameTiler:
         meta[n + 1:n + 1 + k] = self.cost_us[:k]
         meta = meta.to(self.device)
         metas = [torch.empty_like(meta) for _ in range(self.world)]
+        t1 = time.perf_counter()
         dist.all_gather(metas, meta)
         host = torch.stack(metas).cpu()
+        t2 = time.perf_counter()
         counts = host[:, 0].tolist()
         owners, costs = [], []
         for r in range(self.world):
@@ -143,4 +151,8 @@ class FrameTiler:
                 self._place(host[r, 1:1 + len(b)].tolist(), b)
         elif k:
             dist.isend(self.tiles[:k].contiguous(), dst=0).wait()
+        if os.environ.get("SRT_BENCH_DEBUG"):
+            t3 = time.perf_counter()
+            print(f"[rank {self.rank}] gather: wait for tiles {1e3 * (t1 - t0):.1f} ms, tile ids {1e3 * (t2 - t1):.1f} ms, "
+                  f"pixels {1e3 * (t3 - t2):.1f} ms", file=sys.stderr, flush=True)
         self.step += 1

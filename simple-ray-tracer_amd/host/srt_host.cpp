@@ -35,20 +35,21 @@ std::map<int, srt_device*> g_devices;
 
 } // namespace
 
-srt_device* deviceFor(int gpu)
+/* device key = gpu + 1024 * context */
+srt_device* deviceFor(int key)
 {
     std::lock_guard<std::mutex> lock(g_mu);
-    auto it = g_devices.find(gpu);
+    auto it = g_devices.find(key);
     if (it != g_devices.end())
         return it->second;
     srt_device* d = nullptr;
-    if (srt_device_create(gpu, &d) != SRT_OK)
+    if (srt_device_create(key & 1023, &d) != SRT_OK)
         raise("MI355X back end unavailable");
-    g_devices[gpu] = d;
+    g_devices[key] = d;
     return d;
 }
 
-void setDevice(int gpuId) { t_gpu = gpuId; }
+void setDevice(int gpuId, int context) { t_gpu = (gpuId & 1023) + 1024 * context; }
 int currentDevice() { return t_gpu; }
 
 float radians(float degrees) { return degrees * 0.01745329251994329576923690768489f; }

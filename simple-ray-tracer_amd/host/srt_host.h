@@ -179,11 +179,14 @@ Scene loadSceneFromFile(const std::filesystem::path& path, const std::vector<Lig
 
 /* ---- back-end selection and policy (no counterpart in the reference) */
 
-/* GPU used by objects created afterwards on this thread (default 0). */
-void setDevice(int gpuId);
+/* GPU used by objects created afterwards on this thread (default 0).  context selects one of several independent
+ * back-end handles on that GPU (each with its own work buffers and scene copies): renders through BVHs of
+ * different contexts may be in flight at once on different streams, e.g. so that one tile's tail overlaps the
+ * next tile's start. */
+void setDevice(int gpuId, int context = 0);
 int currentDevice();
-/* Lazily created back-end handle of a GPU; throws std::runtime_error when no GPU is usable. */
-srt_device* deviceFor(int gpuId);
+/* Lazily created back-end handle for a value of currentDevice(); throws std::runtime_error when no GPU is usable. */
+srt_device* deviceFor(int deviceKey);
 
 struct RenderOptions {
     bool referenceTraversal = false; /* true: the reference's exact visiting rule (full-tree shadow walks) */

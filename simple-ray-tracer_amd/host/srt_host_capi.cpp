@@ -60,7 +60,8 @@ extern "C" {
 
 const char* srth_last_error(void) { return g_err.c_str(); }
 
-int srth_set_device(int gpu) { SRTH_TRY(setDevice(gpu); (void)deviceFor(gpu)) }
+int srth_set_device(int gpu) { SRTH_TRY(setDevice(gpu); (void)deviceFor(currentDevice())) }
+int srth_set_device_context(int gpu, int context) { SRTH_TRY(setDevice(gpu, context); (void)deviceFor(currentDevice())) }
 
 srth_scene* srth_scene_create(void) { return new srth_scene(); }
 void srth_scene_destroy(srth_scene* s) { delete s; }
