@@ -38,13 +38,17 @@ def workload(name, srt):
         return d, dict(width=3840, height=2160, features=feat, nsx=4, nsy=2, max_depth=5, cpu_block=1,
                        label="dragon stand-in (procedural, 262144 triangles) 3840x2160, 8 spp (4x2 grid), shading + "
                              "hard shadow (point light) + soft shadow (parallelogram light, 100 samples)")
+    scene_file = os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz")
     if name == "teapot":
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import orc
-        d = orc.load_scene_npz(os.path.join(ROOT, "tests", "golden", "scenes", "teapot.npz"))
         feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_MISS_CULL
-        return d, dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=4,
-                       label="teapot 15704 triangles 1920x1080, primary + shadow rays")
+        return standin.load_scene_npz(scene_file), dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=4,
+                                                        label="teapot 15704 triangles 1920x1080, primary + shadow rays")
+    if name in ("monkey", "cube_textured"):
+        feat = (srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_RECURSIVE | srt.F_NORMAL_INTERP | srt.F_TEXTURE
+                | srt.F_MISS_CULL)
+        return standin.load_scene_npz(scene_file), dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=8,
+                                                        label=f"{name} 1920x1080, shading + hard shadows + mirror recursion (depth cap 5) + "
+                                                              "normal interpolation + texture lookup")
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -148,7 +152,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="dragon", choices=["dragon", "teapot"])
+    ap.add_argument("--workload", default="dragon", choices=["dragon", "teapot", "monkey", "cube_textured"])
     ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU, 480x270 otherwise)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -73,6 +73,19 @@ def dragon_standin(nu=1024, nv=128):
     }
 
 
+SCENE_KEYS = ("mesh_vert_off", "mesh_tri_off", "verts", "tris", "materials", "mesh_tex", "tex_w", "tex_h", "tex_off",
+              "texels_u8", "lights")
+
+
+def load_scene_npz(path):
+    """Scene stored as plain arrays (the layout Scene.from_arrays takes) -> dict; texels are expanded to float RGB
+    the way the reference's image loader does it: u8 / 255.0f (reference framework/src/image.cpp:30-32)."""
+    with np.load(path, allow_pickle=False) as z:
+        d = {k: np.ascontiguousarray(z[k]) for k in SCENE_KEYS}
+    d["texels"] = np.ascontiguousarray(d["texels_u8"].astype(np.float32) / np.float32(255.0))
+    return d
+
+
 def point_light(pos, col=(1, 1, 1)):
     l = np.zeros(LIGHT_STRIDE, np.float32)
     l[1:4], l[4:7] = pos, col
