@@ -176,7 +176,7 @@ typedef struct srt_render_params {
 } srt_render_params;
 
 #define SRT_RENDER_STATS (1u << 0)  /* also count node visits / triangle tests (slower kernels) */
-#define SRT_RENDER_TIMING (1u << 1) /* bracket every launch with HIP events for srt_device_last_kernel_ms */
+#define SRT_RENDER_TIMING (1u << 1) /* bracket every launch with HIP events for srt_device_kernel_times */
 
 /* Where a rendered pixel (x, y) goes: element ((out_height - 1 - (y - y0)) * out_width + (x - x0)) of each
  * output array, i.e. Screen::setPixel's layout (reference src/screen.cpp:85-91) for a buffer that covers
@@ -194,6 +194,8 @@ typedef struct srt_output {
 typedef struct srt_device srt_device;
 typedef struct srt_scene srt_scene;
 
+/* Device handles have no counterpart in the reference (it renders on the calling process's CPU threads): a handle
+ * owns the work buffers, counters and timing events of one GPU; several handles may exist per GPU. */
 const char* srt_last_error(void);
 int srt_device_count(int* count);
 int srt_device_create(int gpu_id, srt_device** out);
@@ -211,15 +213,18 @@ int srt_device_read_kernel_counters(srt_device* dev, void* stream, srt_counters 
  * covers.  Waits for the last recorded event.  At most 2048 events are kept between resets. */
 int srt_device_kernel_times(srt_device* dev, float ms[SRT_KERNEL_FAMILIES], int32_t launches[SRT_KERNEL_FAMILIES], int reset);
 
-/* Copies every array of the description to device memory; the host arrays stay with the caller. */
+/* What BvhInterface's constructor leaves behind (reference src/bvh_interface.h:16, src/bounding_volume_hierarchy.cpp:
+ * 14-35: the node table over the Scene's meshes), flattened by the caller; copies every array of the description
+ * to device memory, the host arrays stay with the caller. */
 int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);
 void srt_scene_destroy(srt_scene* scene);
 
-/* renderRayTracing for one rectangle of the frame. */
+/* renderRayTracing (reference src/render.h:17, src/render.cpp:180-234) for one rectangle of the frame. */
 int srt_render(srt_device* dev, srt_scene* scene, const srt_render_params* params, const srt_output* out,
                void* stream);
 
-/* BvhInterface::intersect for n rays (host arrays; 7 floats per ray: origin, direction, t).  The ray's t is
+/* BvhInterface::intersect (reference src/bvh_interface.h:38, src/bounding_volume_hierarchy.cpp:316-393) for n rays
+ * (host arrays; 7 floats per ray: origin, direction, t).  The ray's t is
  * updated in place; hits carries what the reference leaves in HitInfo.  Always counts node visits. */
 int srt_intersect_batch(srt_device* dev, srt_scene* scene, float* rays7, int64_t n, uint32_t features,
                         srt_hit* hits, srt_counters* counters);
@@ -229,7 +234,8 @@ int srt_intersect_batch(srt_device* dev, srt_scene* scene, float* rays7, int64_t
 int srt_final_color_batch(srt_device* dev, srt_scene* scene, const float* rays7, int64_t n, uint32_t features,
                           int32_t max_depth, uint32_t seed, float* rgb);
 
-/* Trackball::generateRay for n normalized pixel positions (host arrays; ndc: 2 floats, rays: 7 floats). */
+/* Trackball::generateRay (reference framework/src/trackball.cpp:101-110) for n normalized pixel positions (host
+ * arrays; ndc: 2 floats, rays: 7 floats). */
 int srt_generate_rays(srt_device* dev, const srt_camera* camera, const float* ndc2, int64_t n, float* rays7);
 
 /* Device self-test (no counterpart in the reference): compares the ray-constant-denominator division used by the
