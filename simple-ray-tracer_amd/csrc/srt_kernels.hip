@@ -831,7 +831,7 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
  * going to consecutive idle lanes, so its lanes keep working on neighbouring samples of the same few hits
  * (same origin, nearby targets on the light). */
 #ifndef SRT_SHADOW_WAVES
-#define SRT_SHADOW_WAVES 6 /* waves per SIMD the register allocation aims at (measured: 4: 249 ms, 6: 231, 7: 229 with spills, 8: 239) */
+#define SRT_SHADOW_WAVES 6 /* waves per SIMD the register allocation aims at (dragon frame's shadow launch: 5 waves 208 ms, 6: 199, 7: 204) */
 #endif
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
