@@ -54,7 +54,11 @@ extern "C" {
  * and both child references.  A child reference is
  *     inner child: index into the node array
  *     leaf child : SRT_LEAF_FLAG | count << 24 | first triangle (position in the leaf-ordered streams)
- * Node 0 is the root when the root is an inner node; nodes are stored breadth first. */
+ * Node 0 is the root when the root is an inner node, and an inner child's index is larger than its parent's:
+ * that is all srt_scene_upload requires of the order (it rejects anything else).  The order decides cache
+ * behaviour only.  The host mirror stores nodes depth first with the RIGHT child directly after its parent (the
+ * traversal enters the right child first, so every second descent stays in the same 128-byte line); that is the
+ * layout all published timings were taken with, and the one to emit. */
 typedef struct srt_node {
     float lbox[6]; /* left child: lower xyz, upper xyz */
     float rbox[6]; /* right child */
@@ -118,7 +122,8 @@ typedef struct srt_scene_desc {
     uint32_t n_nodes;
     float root_box[6];
     uint32_t root_ref;   /* child-reference encoding; a scene with <= 1 triangle has a leaf root */
-    uint32_t num_levels; /* BoundingVolumeHierarchy::numLevels() */
+    uint32_t num_levels; /* BoundingVolumeHierarchy::numLevels(): levels of the tree, leaves included; sizes the
+                            traversal stacks, so an upload whose node table is deeper than this is rejected */
     const srt_tri* tris;
     const srt_tri_attr* attrs;
     uint32_t n_tris;

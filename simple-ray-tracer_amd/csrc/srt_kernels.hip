@@ -1206,7 +1206,7 @@ struct DevBuf {
 struct srt_device {
     int gpu = 0;
     int n_cu = 0;
-    DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family */
+    DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family, plus one for srt_intersect_batch */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
     unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
     DevBuf acc, hq_slot, hq_t, hq_tri, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
@@ -1216,13 +1216,21 @@ struct srt_device {
     bool ev_ready = false;
 };
 
+/* Persistent-grid sizes (blocks that fit the GPU at once) of the four queue kernels. */
+struct Grids {
+    int primary = 0, secondary = 0, shadow = 0, shade = 0;
+};
+
 struct srt_scene {
     srt_device* dev = nullptr;
     SceneDev view {};
     uint32_t num_levels = 0;
+    Grids grids[2][2]; /* [miss culling][counting kernels]; fixed at upload: they depend on the stack depth only */
     std::vector<uint32_t> light_types; /* host copy: sizes the shadow-query stage */
     std::vector<void*> allocs;
 };
+
+static int scene_grids(srt_device* d, srt_scene* sc);
 
 template <typename T>
 static int upload(srt_scene* s, const T* host, size_t count, const T** dev_out)
@@ -1272,13 +1280,13 @@ int srt_device_create(int gpu_id, srt_device** out)
     srt_device* d = new srt_device();
     d->gpu = gpu_id;
     d->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc((void**)&d->counters, SRT_FAMILIES * sizeof(DevCounters));
+    hipError_t e = hipMalloc((void**)&d->counters, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e == hipSuccess)
         e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
     if (e == hipSuccess)
         e = hipMalloc((void**)&d->chunk_counters, 32 * sizeof(unsigned long long));
     if (e == hipSuccess)
-        e = hipMemset(d->counters, 0, SRT_FAMILIES * sizeof(DevCounters));
+        e = hipMemset(d->counters, 0, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e != hipSuccess) {
         delete d;
         return fail(SRT_ERR_HIP, "device set-up failed: %s", hipGetErrorString(e));
@@ -1411,14 +1419,30 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         return fail(SRT_ERR_INVALID, "srt_scene_upload: a non-empty array is null");
     /* Every index a kernel will follow is validated here, on the host, before anything is launched. */
     int rc = check_ref(desc, desc->root_ref, "root");
+    if (rc == SRT_OK && !(desc->root_ref & SRT_LEAF_FLAG) && desc->root_ref != 0)
+        rc = fail(SRT_ERR_INVALID, "an inner root must be node 0 (root reference %u)", desc->root_ref);
+    /* An inner child's index is larger than its parent's, so a traversal cannot cycle, and one pass in index
+     * order gives every inner node's depth: the per-lane stacks hold one pending sibling per inner level and
+     * are sized from num_levels, which therefore must cover the deepest leaf (inner depth + 2 levels). */
+    std::vector<uint32_t> depth(desc->n_nodes, 0);
+    uint32_t deepest = 0;
     for (uint32_t i = 0; i < desc->n_nodes && rc == SRT_OK; ++i) {
         rc = check_ref(desc, desc->nodes[i].left, "left child");
         if (rc == SRT_OK)
             rc = check_ref(desc, desc->nodes[i].right, "right child");
-        /* breadth-first storage: children come after their parent, so a traversal cannot cycle */
-        if (rc == SRT_OK && ((!(desc->nodes[i].left & SRT_LEAF_FLAG) && desc->nodes[i].left <= i) || (!(desc->nodes[i].right & SRT_LEAF_FLAG) && desc->nodes[i].right <= i)))
-            rc = fail(SRT_ERR_INVALID, "node %u: child index does not follow its parent", i);
+        for (uint32_t child : { desc->nodes[i].left, desc->nodes[i].right }) {
+            if (rc != SRT_OK || (child & SRT_LEAF_FLAG))
+                continue;
+            if (child <= i)
+                rc = fail(SRT_ERR_INVALID, "node %u: child index %u does not follow its parent", i, child);
+            else
+                depth[child] = depth[i] + 1;
+        }
+        if (depth[i] > deepest)
+            deepest = depth[i];
     }
+    if (rc == SRT_OK && desc->n_nodes && deepest + 2 > desc->num_levels)
+        rc = fail(SRT_ERR_INVALID, "num_levels is %u but the node table is %u levels deep", desc->num_levels, deepest + 2);
     if (rc != SRT_OK)
         return rc;
     for (uint32_t i = 0; i < desc->n_tris; ++i) {
@@ -1487,6 +1511,11 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     for (uint32_t i = 0; i < desc->n_nodes && fast; ++i)
         fast = box_ok(desc->nodes[i].lbox) && box_ok(desc->nodes[i].rbox);
     v.fast_boxes = fast ? 1u : 0u;
+    rc = scene_grids(dev, s);
+    if (rc != SRT_OK) {
+        srt_scene_destroy(s);
+        return rc;
+    }
     *out = s;
     return SRT_OK;
 }
@@ -1551,24 +1580,27 @@ static uint32_t shadows_per_hit(const srt_scene* sc, uint32_t features)
     return n;
 }
 
+/* Device memory one rectangle's kernels work in, beyond the scene, the inputs and the outputs.  srt_render takes it
+ * from buffers the device handle grows on demand. */
+struct Work {
+    float* acc = nullptr;            /* 3 floats per sample */
+    HitQ hq {};                      /* one entry per sample (more with transparency) */
+    unsigned char* vis = nullptr;    /* one byte per (hit, shadow query) */
+    float4* path[2] = { nullptr, nullptr }; /* 3 float4 per queued path ray; only with reflections / transparency */
+    uint32_t* qcounts = nullptr;     /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
+    unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
+    bool growable = false;           /* the queues may be enlarged between depths (transparency) */
+};
+
 template <bool CULL, bool COUNT>
-static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32_t flags, hipStream_t st)
+static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32_t flags, hipStream_t st, Work wk)
 {
     const size_t lds = stack_bytes(sc);
     const bool timing = (flags & SRT_RENDER_TIMING) != 0;
     const uint32_t n = rp.n_samples;
     const uint32_t sph = shadows_per_hit(sc, rp.features);
-    /* one visibility byte per (hit, shadow sample); every sample of the rectangle may hit */
-    int rc = d->vis.reserve((size_t)n * sph + 64);
-    if (rc != SRT_OK)
-        return rc;
-    int g_primary = 0, g_secondary = 0, g_shadow = 0, g_shade = 0;
-    rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, lds, &g_primary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, lds, &g_secondary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_stack_bytes(sc), &g_shadow);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g_shade);
-    if (rc != SRT_OK)
-        return rc;
+    const Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
+    int g_primary = g.primary, g_secondary = g.secondary, g_shadow = g.shadow, g_shade = g.shade;
     const int need = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
     if (need < g_primary) g_primary = need;
     if (need < g_secondary) g_secondary = need;
@@ -1576,25 +1608,25 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const unsigned long long need_shadow = ((unsigned long long)n * sph + SRT_BLOCK - 1) / SRT_BLOCK;
     if (need_shadow < (unsigned long long)g_shadow) g_shadow = (int)need_shadow;
 
-    HitQ hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
-    uint32_t* hq_count = d->qcounts;
-    uint32_t* path_count = d->qcounts + 32;
-    float* acc = (float*)d->acc.p;
-    unsigned char* vis = (unsigned char*)d->vis.p;
-    HIPCHK(hipMemsetAsync(d->qcounts, 0, 64 * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(d->chunk_counters, 0, 32 * sizeof(unsigned long long), st));
+    HitQ hq = wk.hq;
+    uint32_t* hq_count = wk.qcounts;
+    uint32_t* path_count = wk.qcounts + 32;
+    float* acc = wk.acc;
+    unsigned char* vis = wk.vis;
+    HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 32 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
     mark(d, st, 0, timing);
     hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0);
     const bool branching = (rp.features & SRT_F_TRANSPARENCY) != 0;
     const int last_depth = (rp.features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY)) ? rp.max_depth : 0;
     for (int depth = 0; depth <= last_depth; ++depth) {
-        const float4* cur = (const float4*)d->path[depth & 1].p;
-        float4* nxt = (float4*)d->path[(depth + 1) & 1].p;
+        const float4* cur = wk.path[depth & 1];
+        float4* nxt = wk.path[(depth + 1) & 1];
         if (sph) {
             mark(d, st, 4, timing);
             hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_BLOCK), shadow_stack_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
-                vis, sph, d->counters + 4, d->chunk_counters + depth);
+                vis, sph, d->counters + 4, wk.chunk_counters + depth);
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
@@ -1604,7 +1636,10 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         if (branching) {
             /* A hit may send on two rays, so the queues can outgrow the sample count: read how many rays this
              * depth spawned and make room for their hits, their visibility bytes and twice as many successors.
-             * Everything the buffers held is dead by now (hits, visibility and rays of this depth). */
+             * Everything the buffers held is dead by now (hits, visibility and rays of this depth).  This is the
+             * one place where a frame waits for the device between its launches. */
+            if (!wk.growable)
+                return fail(SRT_ERR_INVALID, "transparency needs queues that can grow");
             uint32_t spawned = 0;
             HIPCHK(hipMemcpyAsync(&spawned, path_count + depth + 1, sizeof spawned, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -1612,7 +1647,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
                 break;
             if (spawned >= (1u << 30))
                 return fail(SRT_ERR_INVALID, "transparency: %u rays at depth %d; render a smaller rectangle", spawned, depth + 1);
-            rc = d->hq_slot.reserve((size_t)spawned * 4);
+            int rc = d->hq_slot.reserve((size_t)spawned * 4);
             if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)spawned * 4);
             if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)spawned * 4);
             if (rc == SRT_OK) rc = d->vis.reserve((size_t)spawned * sph + 64);
@@ -1621,6 +1656,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
                 return rc;
             hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
             vis = (unsigned char*)d->vis.p;
+            wk.path[depth & 1] = (float4*)d->path[depth & 1].p;
         }
         mark(d, st, 1, timing);
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
@@ -1636,14 +1672,73 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     return SRT_OK;
 }
 
-extern "C" {
+template <bool CULL, bool COUNT>
+static int fill_grids(srt_device* d, srt_scene* sc)
+{
+    Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
+    int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, stack_bytes(sc), &g.primary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, stack_bytes(sc), &g.secondary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_stack_bytes(sc), &g.shadow);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g.shade);
+    return rc;
+}
 
-int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const srt_output* out, void* stream)
+/* Called once per scene upload, so that no render call has to query occupancies. */
+static int scene_grids(srt_device* d, srt_scene* sc)
+{
+    int rc = fill_grids<false, false>(d, sc);
+    if (rc == SRT_OK) rc = fill_grids<false, true>(d, sc);
+    if (rc == SRT_OK) rc = fill_grids<true, false>(d, sc);
+    if (rc == SRT_OK) rc = fill_grids<true, true>(d, sc);
+    return rc;
+}
+
+static int dispatch_render(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32_t features, uint32_t flags, hipStream_t st, const Work& wk)
+{
+    const bool cull = (features & SRT_F_MISS_CULL) != 0;
+    const bool stats = (flags & SRT_RENDER_STATS) != 0;
+    if (cull && stats) return render_impl<true, true>(d, sc, rp, flags, st, wk);
+    if (cull) return render_impl<true, false>(d, sc, rp, flags, st, wk);
+    if (stats) return render_impl<false, true>(d, sc, rp, flags, st, wk);
+    return render_impl<false, false>(d, sc, rp, flags, st, wk);
+}
+
+/* Work memory out of the device handle's growable buffers, sized for n samples. */
+static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t features, Work* wk)
+{
+    const uint32_t sph = shadows_per_hit(sc, features);
+    int rc = d->acc.reserve((size_t)n * 12);
+    if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
+    /* one visibility byte per (hit, shadow sample); every sample of the rectangle may hit */
+    if (rc == SRT_OK) rc = d->vis.reserve((size_t)n * sph + 64);
+    if (rc == SRT_OK && (features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
+        /* with transparency a hit may send on two rays */
+        const size_t per = (features & SRT_F_TRANSPARENCY) ? 96 : 48;
+        rc = d->path[0].reserve((size_t)n * per);
+        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
+    }
+    if (rc != SRT_OK)
+        return rc;
+    wk->acc = (float*)d->acc.p;
+    wk->hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
+    wk->vis = (unsigned char*)d->vis.p;
+    wk->path[0] = (float4*)d->path[0].p, wk->path[1] = (float4*)d->path[1].p;
+    wk->qcounts = d->qcounts;
+    wk->chunk_counters = d->chunk_counters;
+    wk->growable = true;
+    return SRT_OK;
+}
+
+/* Checks a render call's arguments and turns them into the kernels' view of the rectangle (everything but the
+ * output pointers). */
+static int rect_setup(srt_device* d, srt_scene* sc, const srt_render_params* p, const srt_output* out, const char* who, RenderDev* rpo)
 {
     if (!d || !sc || !p || !out || !out->rgb)
-        return fail(SRT_ERR_INVALID, "srt_render: null argument");
+        return fail(SRT_ERR_INVALID, "%s: null argument", who);
     if (sc->dev != d)
-        return fail(SRT_ERR_INVALID, "srt_render: scene belongs to another device handle");
+        return fail(SRT_ERR_INVALID, "%s: scene belongs to another device handle", who);
     const srt_camera& cam = p->camera;
     if (cam.width <= 0 || cam.height <= 0)
         return fail(SRT_ERR_INVALID, "camera resolution %dx%d", cam.width, cam.height);
@@ -1666,23 +1761,6 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
         return fail(SRT_ERR_INVALID, "rectangle holds %llu samples; split it below 2^31", (unsigned long long)n64);
     if ((uint64_t)cam.width * cam.height * (uint64_t)(nsx * nsy) >= (1ull << 32))
         return fail(SRT_ERR_INVALID, "frame holds more than 2^32 samples");
-    HIPCHK(hipSetDevice(d->gpu));
-    hipStream_t st = (hipStream_t)stream;
-    const uint32_t n = (uint32_t)n64;
-
-    int rc = d->acc.reserve((size_t)n * 12);
-    if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
-    if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
-    if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
-    if (rc == SRT_OK && (p->features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
-        /* with transparency a hit may send on two rays */
-        const size_t per = (p->features & SRT_F_TRANSPARENCY) ? 96 : 48;
-        rc = d->path[0].reserve((size_t)n * per);
-        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
-    }
-    if (rc != SRT_OK)
-        return rc;
-
     RenderDev rp {};
     rp.cam = cam;
     rp.features = p->features;
@@ -1690,8 +1768,26 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
     rp.max_depth = p->max_depth;
     rp.seed = p->seed;
     rp.x0 = x0, rp.y0 = y0, rp.tw = x1 - x0, rp.th = y1 - y0;
-    rp.n_samples = n;
+    rp.n_samples = (uint32_t)n64;
     rp.out_w = out->out_width, rp.out_h = out->out_height, rp.out_x0 = out->x0, rp.out_y0 = out->y0;
+    *rpo = rp;
+    return SRT_OK;
+}
+
+extern "C" {
+
+int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const srt_output* out, void* stream)
+{
+    RenderDev rp {};
+    int rc = rect_setup(d, sc, p, out, "srt_render", &rp);
+    if (rc != SRT_OK)
+        return rc;
+    HIPCHK(hipSetDevice(d->gpu));
+    hipStream_t st = (hipStream_t)stream;
+    Work wk;
+    rc = handle_work(d, sc, rp.n_samples, p->features, &wk);
+    if (rc != SRT_OK)
+        return rc;
     const size_t out_px = (size_t)out->out_width * out->out_height;
     if (out->on_device) {
         rp.out_rgb = out->rgb, rp.out_mesh = out->prim_mesh, rp.out_tri = out->prim_tri, rp.out_t = out->prim_t;
@@ -1713,12 +1809,7 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
         if (rp.out_tri) HIPCHK(hipMemcpyAsync(rp.out_tri, out->prim_tri, out_px * 4, hipMemcpyHostToDevice, st));
         if (rp.out_t) HIPCHK(hipMemcpyAsync(rp.out_t, out->prim_t, out_px * 4, hipMemcpyHostToDevice, st));
     }
-    const bool cull = (p->features & SRT_F_MISS_CULL) != 0;
-    const bool stats = (p->flags & SRT_RENDER_STATS) != 0;
-    if (cull && stats) rc = render_impl<true, true>(d, sc, rp, p->flags, st);
-    else if (cull) rc = render_impl<true, false>(d, sc, rp, p->flags, st);
-    else if (stats) rc = render_impl<false, true>(d, sc, rp, p->flags, st);
-    else rc = render_impl<false, false>(d, sc, rp, p->flags, st);
+    rc = dispatch_render(d, sc, rp, p->features, p->flags, st, wk);
     if (rc != SRT_OK)
         return rc;
     if (!out->on_device) {
@@ -1748,8 +1839,7 @@ int srt_intersect_batch(srt_device* d, srt_scene* sc, float* rays7, int64_t n, u
     if (rc != SRT_OK)
         return rc;
     HIPCHK(hipMemcpy(d->io_a.p, rays7, (size_t)n * 28, hipMemcpyHostToDevice));
-    DevCounters* tmp = nullptr;
-    HIPCHK(hipMalloc((void**)&tmp, sizeof(DevCounters)));
+    DevCounters* tmp = d->counters + SRT_FAMILIES; /* the handle's slot for this entry point */
     hipError_t e = hipMemset(tmp, 0, sizeof(DevCounters));
     const size_t lds = stack_bytes(sc);
     int grid = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
@@ -1767,7 +1857,6 @@ int srt_intersect_batch(srt_device* d, srt_scene* sc, float* rays7, int64_t n, u
     if (e == hipSuccess) e = hipMemcpy(hits, d->io_b.p, (size_t)n * sizeof(srt_hit), hipMemcpyDeviceToHost);
     DevCounters c {};
     if (e == hipSuccess) e = hipMemcpy(&c, tmp, sizeof c, hipMemcpyDeviceToHost);
-    (void)hipFree(tmp);
     if (e != hipSuccess)
         return fail(SRT_ERR_HIP, "srt_intersect_batch: %s", hipGetErrorString(e));
     if (counters) {
@@ -1791,15 +1880,8 @@ int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int6
     HIPCHK(hipSetDevice(d->gpu));
     int rc = d->io_a.reserve((size_t)n * 28);
     if (rc == SRT_OK) rc = d->io_b.reserve((size_t)n * 12);
-    if (rc == SRT_OK) rc = d->acc.reserve((size_t)n * 12);
-    if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
-    if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
-    if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
-    if (rc == SRT_OK && (features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
-        const size_t per = (features & SRT_F_TRANSPARENCY) ? 96 : 48;
-        rc = d->path[0].reserve((size_t)n * per);
-        if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
-    }
+    Work wk;
+    if (rc == SRT_OK) rc = handle_work(d, sc, (uint32_t)n, features, &wk);
     if (rc != SRT_OK)
         return rc;
     HIPCHK(hipMemcpy(d->io_a.p, rays7, (size_t)n * 28, hipMemcpyHostToDevice));
@@ -1814,10 +1896,7 @@ int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int6
     rp.out_rgb = (float*)d->io_b.p;
     rp.out_w = (int32_t)n, rp.out_h = 1;
     rp.custom_rays = (const float*)d->io_a.p;
-    if (features & SRT_F_MISS_CULL)
-        rc = render_impl<true, false>(d, sc, rp, 0, 0);
-    else
-        rc = render_impl<false, false>(d, sc, rp, 0, 0);
+    rc = dispatch_render(d, sc, rp, features, 0, 0, wk);
     if (rc != SRT_OK)
         return rc;
     HIPCHK(hipMemcpy(rgb, d->io_b.p, (size_t)n * 12, hipMemcpyDeviceToHost));

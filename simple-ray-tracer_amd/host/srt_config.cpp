@@ -168,6 +168,16 @@ static float number(const toml::Value& v, float fallback)
     return fallback;
 }
 
+/* An integer key of the [mi355x] table: absent -> fallback; anything but a TOML integer inside [lo, hi] is an error. */
+static int64_t integerKey(const toml::Value& v, const char* key, int64_t fallback, int64_t lo, int64_t hi)
+{
+    if (v.kind == toml::Value::None)
+        return fallback;
+    if (v.kind != toml::Value::Int || v.i < lo || v.i > hi)
+        throw std::runtime_error(std::string("configuration: mi355x.") + key + " must be an integer in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+    return v.i;
+}
+
 static Config fromTable(const toml::Value& table)
 {
     Config config = {};
@@ -258,10 +268,10 @@ static Config fromTable(const toml::Value& table)
     const toml::Value& backend = table["mi355x"];
     if (backend.kind == toml::Value::TableKind) {
         BackendConfig& b = config.backend;
-        b.gpu = (int)number(backend["gpu"], 0.0f);
-        b.numRays = (int)number(backend["num_rays"], 1.0f);
-        b.maxDepth = (int)number(backend["max_depth"], 5.0f);
-        b.seed = (uint32_t)number(backend["seed"], 0.0f);
+        b.gpu = (int)integerKey(backend["gpu"], "gpu", 0, 0, 1023);
+        b.numRays = (int)integerKey(backend["num_rays"], "num_rays", 1, 1, 64);
+        b.maxDepth = (int)integerKey(backend["max_depth"], "max_depth", 5, 0, 30);
+        b.seed = (uint32_t)integerKey(backend["seed"], "seed", 0, 0, 0xFFFFFFFFll);
         optionalBool(backend["enable_soft_shadow"], b.enableSoftShadow);
         optionalBool(backend["enable_transparency"], b.enableTransparency);
         if (backend["traversal"].kind == toml::Value::String) {
@@ -270,8 +280,6 @@ static Config fromTable(const toml::Value& table)
             else if (backend["traversal"].s != "miss-cull")
                 throw std::runtime_error("configuration: mi355x.traversal must be \"reference\" or \"miss-cull\"");
         }
-        if (b.numRays < 1 || b.maxDepth < 0)
-            throw std::runtime_error("configuration: mi355x.num_rays must be at least 1 and mi355x.max_depth at least 0");
     }
     return config;
 }

@@ -192,8 +192,10 @@ size_t BoundingVolumeHierarchy::constructorHelper(std::vector<Node>& out, std::v
         constructorHelper(l, triangles, left, median, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
 #pragma omp task shared(r, triangles)
         constructorHelper(r, triangles, median, right, (whichAxis + 1) % 3, level + 1, forkLevels - 1);
-        const AxisAlignedBox box = getBox(triangles, left, right);
 #pragma omp taskwait
+        /* after the children, as in the reference: they re-sort their halves of the range in place, and reading
+         * the range while they do would be a race */
+        const AxisAlignedBox box = getBox(triangles, left, right);
         return splice(out, l, r, { false, level, { { 0, 0, 0 }, { 0, 0, 0 } }, box });
     }
     const size_t leftIndex = constructorHelper(out, triangles, left, median, (whichAxis + 1) % 3, level + 1, 0);

@@ -12,9 +12,17 @@ import numpy as np
 
 LIGHT_STRIDE = 22
 
+# SHA-256 of dragon_standin()'s default `verts` and `tris` arrays (C order, little endian): the geometry every
+# published dragon number was measured on.  dragon_standin(check=True) refuses to hand out anything else.
+DRAGON_STANDIN_SHA256 = {
+    "verts": "2afc533ca39bf5a8d22ee96dcf149c03c9a40c33829330cb529a6e18be642449",
+    "tris": "00a1ca6a1023d821bdd573a272c35de5477dfc9fd9d7f94bf825f959d4b18511",
+}
 
-def dragon_standin(nu=1024, nv=128):
-    """Returns the scene in the fixture layout (one mesh, no lights)."""
+
+def dragon_standin(nu=1024, nv=128, check=False):
+    """Returns the scene in the fixture layout (one mesh, no lights).  check: raise unless the default grid's
+    arrays carry the pinned hashes (numpy's sin / cos could round differently on another build)."""
     u = (np.arange(nu, dtype=np.float64) / nu) * 2.0 * np.pi
     v = (np.arange(nv, dtype=np.float64) / nv) * 2.0 * np.pi
 
@@ -60,6 +68,11 @@ def dragon_standin(nu=1024, nv=128):
     verts = np.zeros((len(pos), 8), np.float32)
     verts[:, 0:3] = pos
     verts[:, 3:6] = nrm
+    if check:
+        import hashlib
+        for key, arr in (("verts", verts), ("tris", tris)):
+            if (nu, nv) != (1024, 128) or hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest() != DRAGON_STANDIN_SHA256[key]:
+                raise RuntimeError(f"dragon stand-in: `{key}` differs from the pinned geometry")
     return {
         "mesh_vert_off": np.array([0, len(verts)], np.uint32),
         "mesh_tri_off": np.array([0, len(tris)], np.uint32),

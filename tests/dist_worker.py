@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def main():
     out_path, frames = sys.argv[1], int(sys.argv[2])
+    late = int(sys.argv[3]) if len(sys.argv) > 3 else -1  # this rank only asks for tiles once the others have run dry
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo")
     srt = importlib.import_module("simple-ray-tracer_amd")
@@ -42,7 +43,11 @@ def main():
 
     taken = []
     for _ in range(frames):
+        if rank == late:
+            dist.barrier()
         k = ft.render(render_tile)
+        if late >= 0 and rank != late:
+            dist.barrier()
         taken.append(k)
         ft.gather(k)
     counts = torch.tensor(taken, dtype=torch.int64)

@@ -51,17 +51,32 @@ def test_single_rank_tiler_assembles_frame():
     assert np.array_equal(ft.frame[..., 0].numpy(), want)
 
 
-def test_two_ranks_gloo(tmp_path):
+def _run_ranks(tmp_path, ranks, *worker_args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = tmp_path / "frame.npz"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(out), "3"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(out), *worker_args]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    z = np.load(out)
+    return np.load(out)
+
+
+def test_three_ranks_one_without_tiles(tmp_path):
+    """Uneven split: rank 2 only asks for tiles after ranks 0 and 1 have drawn them all, so it takes part in the
+    gather with nothing to send, frame after frame."""
+    z = _run_ranks(tmp_path, 3, "2", "2")
+    assert np.array_equal(z["frame"].view(np.uint32), z["whole"].view(np.uint32))
+    counts = z["counts"]  # [rank, frame]
+    assert counts.shape == (3, 2) and (counts[2] == 0).all() and (counts[:2] > 0).all()
+    assert (counts.sum(0) == int(z["n_tiles"])).all()
+    assert (z["orders"] == z["orders"][0]).all()
+
+
+def test_two_ranks_gloo(tmp_path):
+    z = _run_ranks(tmp_path, 2, "3")
     assert np.array_equal(z["frame"].view(np.uint32), z["whole"].view(np.uint32))  # assembled frame == one-piece frame
     counts = z["counts"]  # [rank, frame]
     assert (counts.sum(0) == int(z["n_tiles"])).all()  # every frame: all tiles, none twice
