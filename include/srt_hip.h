@@ -228,6 +228,22 @@ void srt_scene_destroy(srt_scene* scene);
 int srt_render(srt_device* dev, srt_scene* scene, const srt_render_params* params, const srt_output* out,
                void* stream);
 
+/* srt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same kernels and
+ * bit-identical pixels, but the rectangle's work memory (sample accumulators, hit and path queues, visibility
+ * bytes, queue counters) is carved out of one fixed device array of SRT_NOALLOC_SCRATCH_BYTES that the library
+ * holds on every GPU it is loaded on until the process ends; the call makes no hipMalloc / hipFree.
+ * Limits, each refused with SRT_ERR_INVALID and a message: the output must be device memory (out->on_device = 1);
+ * no SRT_F_TRANSPARENCY and no SRT_RENDER_TIMING; the rectangle must fit the array: about
+ * sample_slots * (24 + 96 with SRT_F_RECURSIVE + shadow queries per hit) bytes, sample_slots = the rectangle padded to
+ * whole 8 x 8-pixel blocks times samples per pixel (e.g. 256 x 256 pixels at 8 samples with 101 shadow queries).
+ * Every call on a GPU uses that GPU's one array, whatever the handle or stream: calls that overlap on one GPU
+ * race; serialize them (one stream, or events).  The array keeps the previous call's contents; the call clears
+ * what it needs cleared. */
+#define SRT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int srt_render_noalloc(srt_device* dev, srt_scene* scene, const srt_render_params* params, const srt_output* out,
+                       void* stream);
+
 /* BvhInterface::intersect (reference src/bvh_interface.h:38, src/bounding_volume_hierarchy.cpp:316-393) for n rays
  * (host arrays; 7 floats per ray: origin, direction, t).  The ray's t is
  * updated in place; hits carries what the reference leaves in HitInfo.  Always counts node visits. */

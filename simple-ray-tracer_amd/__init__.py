@@ -86,7 +86,7 @@ assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 96 and ATTR_DTYPE.ite
 HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "srt_device_destroy",
                    "srt_device_synchronize", "srt_device_read_counters", "srt_device_read_kernel_counters",
                    "srt_device_kernel_times",
-                   "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_intersect_batch",
+                   "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_render_noalloc", "srt_intersect_batch",
                    "srt_final_color_batch", "srt_generate_rays", "srt_selftest_division")
 
 
@@ -139,6 +139,7 @@ def host():
     L.srth_camera_make.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, C.POINTER(Camera)]
     L.srth_generate_rays.argtypes = [C.POINTER(Camera), _f32p, C.c_int64, _f32p]
     L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
+    L.srth_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
     L.srth_read_kernel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
     L.srth_kernel_times.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int]
@@ -383,6 +384,13 @@ class Bvh:
         o.rgb = rgb_ptr
         o.out_width, o.out_height, o.x0, o.y0, o.on_device = out_w, out_h, x0, y0, 1
         _check(host().srth_render(self.h, C.byref(params), C.byref(o), stream))
+
+    def render_device_noalloc(self, params, rgb_ptr, out_w, out_h, x0, y0, stream=None):
+        """render_device through the entry point that allocates nothing (fixed scratch area, bounded rectangle)."""
+        o = Output()
+        o.rgb = rgb_ptr
+        o.out_width, o.out_height, o.x0, o.y0, o.on_device = out_w, out_h, x0, y0, 1
+        _check(host().srth_render_noalloc(self.h, C.byref(params), C.byref(o), stream))
 
     def read_counters(self, stream=None, reset=False):
         c = Counters()

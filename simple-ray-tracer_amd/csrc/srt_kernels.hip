@@ -40,6 +40,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1203,6 +1204,16 @@ struct DevBuf {
 #define SRT_MAX_EVENTS 2048
 #define SRT_FAMILIES SRT_KERNEL_FAMILIES /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve, 4 shadow trace */
 
+/* ---- work memory of the entry point that allocates nothing (srt_render_noalloc).
+ * A file-scope device array: every GPU the library is loaded on holds its own copy, at its own address, until the
+ * process ends.  Host code never passes the array's name to a kernel or a memset (in host code the name is only a
+ * handle for hipGetSymbolAddress); the address is looked up once per GPU in srt_device_create, with that GPU
+ * current, and kept in g_scratch_ptr. */
+static __device__ __align__(256) unsigned char scratch[SRT_NOALLOC_SCRATCH_BYTES];
+#define SRT_MAX_GPUS 64
+static unsigned char* g_scratch_ptr[SRT_MAX_GPUS];
+static std::mutex g_scratch_mu;
+
 struct srt_device {
     int gpu = 0;
     int n_cu = 0;
@@ -1280,6 +1291,18 @@ int srt_device_create(int gpu_id, srt_device** out)
     srt_device* d = new srt_device();
     d->gpu = gpu_id;
     d->n_cu = prop.multiProcessorCount;
+    if (gpu_id < SRT_MAX_GPUS) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[gpu_id]) {
+            void* p = nullptr;
+            hipError_t es = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (es != hipSuccess || !p) {
+                delete d;
+                return fail(SRT_ERR_HIP, "hipGetSymbolAddress(scratch) on GPU %d: %s", gpu_id, hipGetErrorString(es));
+            }
+            g_scratch_ptr[gpu_id] = (unsigned char*)p;
+        }
+    }
     hipError_t e = hipMalloc((void**)&d->counters, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e == hipSuccess)
         e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
@@ -1581,7 +1604,7 @@ static uint32_t shadows_per_hit(const srt_scene* sc, uint32_t features)
 }
 
 /* Device memory one rectangle's kernels work in, beyond the scene, the inputs and the outputs.  srt_render takes it
- * from buffers the device handle grows on demand. */
+ * from buffers the device handle grows on demand, srt_render_noalloc from the static scratch array. */
 struct Work {
     float* acc = nullptr;            /* 3 floats per sample */
     HitQ hq {};                      /* one entry per sample (more with transparency) */
@@ -1820,6 +1843,53 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
         HIPCHK(hipStreamSynchronize(st));
     }
     return SRT_OK;
+}
+
+int srt_render_noalloc(srt_device* d, srt_scene* sc, const srt_render_params* p, const srt_output* out, void* stream)
+{
+    RenderDev rp {};
+    int rc = rect_setup(d, sc, p, out, "srt_render_noalloc", &rp);
+    if (rc != SRT_OK)
+        return rc;
+    if (!out->on_device)
+        return fail(SRT_ERR_INVALID, "srt_render_noalloc: the output must be device memory (host output needs staging buffers; use srt_render)");
+    if (p->features & SRT_F_TRANSPARENCY)
+        return fail(SRT_ERR_INVALID, "srt_render_noalloc: transparency needs queues that grow with the frame; use srt_render");
+    if (p->flags & SRT_RENDER_TIMING)
+        return fail(SRT_ERR_INVALID, "srt_render_noalloc: SRT_RENDER_TIMING creates events; use srt_render");
+    if (d->gpu >= SRT_MAX_GPUS || !g_scratch_ptr[d->gpu])
+        return fail(SRT_ERR_INVALID, "srt_render_noalloc: no scratch address for GPU %d", d->gpu);
+    /* carve the rectangle's work memory out of the scratch array, every piece 256-byte aligned */
+    const uint32_t n = rp.n_samples;
+    const uint32_t sph = shadows_per_hit(sc, p->features);
+    const bool paths = (p->features & SRT_F_RECURSIVE) != 0;
+    unsigned char* const base = g_scratch_ptr[d->gpu];
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        unsigned char* q = base + off;
+        off += (bytes + 255) & ~(size_t)255;
+        return q;
+    };
+    Work wk;
+    wk.qcounts = (uint32_t*)carve(64 * sizeof(uint32_t));
+    wk.chunk_counters = (unsigned long long*)carve(32 * sizeof(unsigned long long));
+    wk.acc = (float*)carve((size_t)n * 12);
+    wk.hq.slot = (uint32_t*)carve((size_t)n * 4);
+    wk.hq.t = (float*)carve((size_t)n * 4);
+    wk.hq.tri = (uint32_t*)carve((size_t)n * 4);
+    wk.vis = carve((size_t)n * sph + 64);
+    if (paths) {
+        wk.path[0] = (float4*)carve((size_t)n * 48);
+        wk.path[1] = (float4*)carve((size_t)n * 48);
+    }
+    if (off > (size_t)SRT_NOALLOC_SCRATCH_BYTES)
+        return fail(SRT_ERR_INVALID, "srt_render_noalloc: the rectangle's %u sample slots need %zu bytes of work memory, the fixed scratch area holds %zu: "
+                                     "render a smaller rectangle or use srt_render", n, off, (size_t)SRT_NOALLOC_SCRATCH_BYTES);
+    HIPCHK(hipSetDevice(d->gpu));
+    rp.out_rgb = out->rgb, rp.out_mesh = out->prim_mesh, rp.out_tri = out->prim_tri, rp.out_t = out->prim_t;
+    /* render_impl clears the queue counts, the chunk counters and the accumulators of this call; everything else
+     * in the area is written before it is read */
+    return dispatch_render(d, sc, rp, p->features, p->flags, (hipStream_t)stream, wk);
 }
 
 int srt_intersect_batch(srt_device* d, srt_scene* sc, float* rays7, int64_t n, uint32_t features, srt_hit* hits, srt_counters* counters)

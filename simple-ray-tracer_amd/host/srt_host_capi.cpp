@@ -297,6 +297,16 @@ int srth_render(const srth_bvh* b, const srt_render_params* params, const srt_ou
     return 0;
 }
 
+/* The same through srt_render_noalloc (device output only, bounded rectangle, no allocation). */
+int srth_render_noalloc(const srth_bvh* b, const srt_render_params* params, const srt_output* out, void* stream)
+{
+    if (srt_render_noalloc(b->bvh->device(), b->bvh->deviceScene(), params, out, stream) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
 int srth_read_counters(const srth_bvh* b, void* stream, srt_counters* out, int reset)
 {
     if (srt_device_read_counters(b->bvh->device(), stream, out, reset) != SRT_OK) {
