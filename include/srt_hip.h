@@ -215,7 +215,7 @@ int srt_device_read_counters(srt_device* dev, void* stream, srt_counters* out, i
 int srt_device_read_kernel_counters(srt_device* dev, void* stream, srt_counters out[SRT_KERNEL_FAMILIES], int reset);
 /* Device time per kernel family, summed over every srt_render call made with SRT_RENDER_TIMING since the last
  * reset (HIP events recorded on each call's own stream around every launch), and the number of launches it
- * covers.  Waits for the last recorded event.  At most 2048 events are kept between resets. */
+ * covers.  Waits for the last recorded event.  At most 8192 events are kept between resets. */
 int srt_device_kernel_times(srt_device* dev, float ms[SRT_KERNEL_FAMILIES], int32_t launches[SRT_KERNEL_FAMILIES], int reset);
 
 /* What BvhInterface's constructor leaves behind (reference src/bvh_interface.h:16, src/bounding_volume_hierarchy.cpp:
@@ -263,6 +263,14 @@ int srt_generate_rays(srt_device* dev, const srt_camera* camera, const float* nd
  * fast slab test with plain IEEE division on n pseudo-random operand pairs drawn from the ranges that path is
  * restricted to; mismatches counts results that differ in more than the sign of a zero (expected: 0). */
 int srt_selftest_division(srt_device* dev, uint32_t seed, uint64_t n, uint64_t* mismatches);
+
+/* Measurement aid (no counterpart in the reference): the rate, in GB/s, at which this GPU serves gathers of 64-byte
+ * records (four 16-byte loads per lane, the shape of a node visit) drawn uniformly from the first window_bytes of
+ * the uploaded node array followed by the triangle stream, with no arithmetic in between; 0 or a window beyond
+ * the records means all of them.  A window of one or two MiB stays in every XCD's L2 (the L2 gather ceiling the
+ * traversal kernels are priced against); the full window shows what a walk without any locality would get. */
+int srt_probe_gather(srt_device* dev, srt_scene* scene, uint64_t window_bytes, uint32_t loads_per_lane,
+                     double* gbytes_per_s, uint64_t* window_used);
 
 #ifdef __cplusplus
 }

@@ -5,11 +5,17 @@ usage: summarize.py <prof_dir> <title> > profiles/<name>.txt"""
 import collections
 import csv
 import glob
+import json
 import sqlite3
 import sys
 
 base, title = sys.argv[1], sys.argv[2]
 print(f"# {title}")
+try:
+    print("# kernel-source-sha256: " + open(base + "/source_hash.txt").read().strip())
+    print("# workload: " + json.loads(open(base + "/bench_line.json").read())["config"]["workload"])
+except (OSError, ValueError, KeyError):
+    pass  # profile directories written before these files existed
 print("# kernel stats: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
 print("# PMC: one rocprofv3 --pmc run per counter group, bench.py --steps 1 --warmup 0 (1 timed + 1 counting frame);")
 print("#      per_launch = value summed over the kernel's launches / number of launches")

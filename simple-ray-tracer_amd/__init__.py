@@ -87,7 +87,7 @@ HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "s
                    "srt_device_synchronize", "srt_device_read_counters", "srt_device_read_kernel_counters",
                    "srt_device_kernel_times",
                    "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_render_noalloc", "srt_intersect_batch",
-                   "srt_final_color_batch", "srt_generate_rays", "srt_selftest_division")
+                   "srt_final_color_batch", "srt_generate_rays", "srt_selftest_division", "srt_probe_gather")
 
 
 def build():
@@ -141,6 +141,7 @@ def host():
     L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
+    L.srth_probe_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.srth_read_kernel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
     L.srth_kernel_times.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int]
     L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
@@ -413,6 +414,12 @@ class Bvh:
 
     def synchronize(self, stream=None):
         _check(host().srth_synchronize(self.h, stream))
+
+    def probe_gather(self, window_bytes=0, loads_per_lane=256):
+        """GB/s of 64-byte record gathers over the first window_bytes of the node + triangle records (0: all)."""
+        gbs, used = C.c_double(), C.c_uint64()
+        _check(host().srth_probe_gather(self.h, int(window_bytes), int(loads_per_lane), C.byref(gbs), C.byref(used)))
+        return float(gbs.value), int(used.value)
 
 
 def make_camera(width, height, fovy_deg=50.0, dist=3.0, look_at=(0, 0, 0), rot_deg=(20, 20, 0)):

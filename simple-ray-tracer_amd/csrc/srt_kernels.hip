@@ -1155,6 +1155,36 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_selftest_division(uint32_t seed, 
         atomicAdd(mismatches, bad);
 }
 
+/* Bandwidth probe: every lane reads `loads` pseudo-random 64-byte records (four 16-byte loads, as a node visit
+ * does) from the first `n_nodes64` 64-byte units of the node array followed by the first `n_tris64` units of the
+ * triangle stream, eight records in flight per lane, and does nothing else with them.  What comes out is the rate at
+ * which the cache level that holds the chosen window can feed gathers of this shape. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_probe_gather(const float4* __restrict__ nodes, uint32_t n_nodes64, const float4* __restrict__ tris,
+                                                              uint32_t n_tris64, uint32_t loads, uint32_t seed, float* sink)
+{
+    const uint32_t tid = blockIdx.x * SRT_BLOCK + threadIdx.x;
+    const uint32_t n = n_nodes64 + n_tris64;
+    float acc = 0.0f;
+    uint32_t h = mix32(seed, tid);
+    for (uint32_t it = 0; it < loads; it += 8) {
+        float4 q[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const uint32_t idx = (uint32_t)(((unsigned long long)(h ^ (h >> 15)) * n) >> 32);
+            const float4* rec = idx < n_nodes64 ? nodes + 4ull * idx : tris + 4ull * (idx - n_nodes64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                q[u][k] = rec[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc += (q[u][0].x + q[u][1].y) + (q[u][2].z + q[u][3].w);
+    }
+    if (acc == 12345.678f)
+        sink[0] = acc; /* keeps the loads alive; practically never taken */
+}
+
 /* ------------------------------------------------------------------------------------------ host side */
 
 static thread_local std::string g_err;
@@ -1201,7 +1231,7 @@ struct DevBuf {
     }
 };
 
-#define SRT_MAX_EVENTS 2048
+#define SRT_MAX_EVENTS 8192
 #define SRT_FAMILIES SRT_KERNEL_FAMILIES /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve, 4 shadow trace */
 
 /* ---- work memory of the entry point that allocates nothing (srt_render_noalloc).
@@ -1991,6 +2021,45 @@ int srt_selftest_division(srt_device* d, uint32_t seed, uint64_t n, uint64_t* mi
     if (e != hipSuccess)
         return fail(SRT_ERR_HIP, "srt_selftest_division: %s", hipGetErrorString(e));
     *mismatches = host;
+    return SRT_OK;
+}
+
+int srt_probe_gather(srt_device* d, srt_scene* sc, uint64_t window_bytes, uint32_t loads_per_lane, double* gbytes_per_s, uint64_t* window_used)
+{
+    if (!d || !sc || !gbytes_per_s || sc->dev != d)
+        return fail(SRT_ERR_INVALID, "srt_probe_gather: bad argument");
+    const uint64_t node_units = sc->view.n_nodes, tri_units = (uint64_t)sc->view.n_tris * 96 / 64;
+    if (node_units + tri_units == 0)
+        return fail(SRT_ERR_INVALID, "srt_probe_gather: the scene has no records");
+    uint64_t units = window_bytes / 64;
+    if (units == 0 || units > node_units + tri_units)
+        units = node_units + tri_units;
+    const uint32_t n_nodes64 = (uint32_t)(units < node_units ? units : node_units);
+    const uint32_t n_tris64 = (uint32_t)(units - n_nodes64);
+    loads_per_lane = (loads_per_lane + 7u) & ~7u;
+    if (loads_per_lane == 0)
+        loads_per_lane = 64;
+    HIPCHK(hipSetDevice(d->gpu));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    const int grid = d->n_cu * 8;
+    float* sink = (float*)(d->counters + SRT_FAMILIES);
+    /* one untimed pass brings the window into the caches it fits */
+    hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 1u, sink);
+    hipError_t e = hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 2u, sink);
+    if (e == hipSuccess) e = hipEventRecord(e1, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess || !(ms > 0))
+        return fail(SRT_ERR_HIP, "srt_probe_gather: %s", hipGetErrorString(e));
+    *gbytes_per_s = (double)grid * SRT_BLOCK * loads_per_lane * 64.0 / (ms * 1e-3) / 1e9;
+    if (window_used)
+        *window_used = units * 64;
     return SRT_OK;
 }
 

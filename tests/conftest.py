@@ -3,6 +3,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first: PyTorch ships its own HIP runtime, and its device initialisation fails in a process
+              # that has already loaded the system one through libsrt_hip.so; some GPU tests use torch device buffers)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")

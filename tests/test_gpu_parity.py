@@ -441,6 +441,51 @@ def test_dragon_8k_64spp_window(orc, dragon_pair):
     assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
 
 
+def test_dragon_8k_64spp_window_with_reflections(orc, dragon_pair):
+    """The same window of the stress frame as its bench workload renders it: mirror recursion to the reference's
+    depth cap on top (ks = 0.2 on the whole model, so every hit sends a reflection ray into the 18-level tree)."""
+    d, ob, gb = dragon_pair
+    feat = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_RECURSIVE | srt.F_MISS_CULL
+    rect = (4004, 3690, 4052, 3714)
+    want = ob.render(orc.make_camera(7680, 4320), feat, nsx=8, nsy=8, rect=rect, max_depth=5)
+    got = gb.render(srt.make_camera(7680, 4320), feat, nsx=8, nsy=8, rect=rect, max_depth=5)
+    ys, xs = slice(4320 - rect[3], 4320 - rect[1]), slice(rect[0], rect[2])
+    sub = lambda r: {k: (v[ys, xs] if isinstance(v, np.ndarray) else v) for k, v in r.items()}
+    _compare_frames(sub(got), sub(want), "8K 64 spp window with reflections")
+    wc, gc = want["counters"], got["counters"]
+    assert (gc["path_rays"], gc["shadow_rays"], gc["shaded_hits"]) == (wc["path_rays"], wc["shadow_rays"], wc["shaded_hits"])
+    assert gc["path_rays"] > 48 * 24 * 64 + 1000  # reflection rays were traced
+
+
+def test_dragon_8k_full_frame_properties(dragon_pair):
+    """The whole 7680 x 4320, 64 spp stress frame with reflections (2.12 G camera rays), rendered the way the bench
+    renders it: 960 x 540 rectangles straight into one frame buffer in HBM.  Size-independent checks: ray totals
+    follow from the hit count, a strip cut differently is bit-identical, pixels are finite and not black."""
+    import torch
+    _, _, gb = dragon_pair
+    W, H = 7680, 4320
+    cam = srt.make_camera(W, H)
+    feat = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_RECURSIVE | srt.F_MISS_CULL
+    tiling = importlib.import_module("simple-ray-tracer_amd.distributed")
+    frame = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    gb.read_counters(reset=True)
+    for rect in tiling.tile_rects(W, H, 960, 540):
+        gb.render_device(gb.params(cam, feat, 8, 8, 5, 0, rect, 0), frame.data_ptr(), W, H, 0, 0, stream)
+    torch.cuda.synchronize()
+    c = gb.read_counters(reset=True)
+    n = W * H * 64
+    assert n < c["path_rays"] <= n + c["shaded_hits"]  # every hit below the depth cap reflects once
+    assert c["shadow_rays"] == 101 * c["shaded_hits"] and c["shaded_hits"] > 0.1 * n
+    strip = torch.zeros((64, W, 3), dtype=torch.float32, device="cuda")
+    y0 = 2130  # a strip across all eight columns of rectangles and across the boundary between two of their rows (y = 2160)
+    gb.render_device(gb.params(cam, feat, 8, 8, 5, 0, (0, y0, W, y0 + 64), 0), strip.data_ptr(), W, 64, 0, y0, stream)
+    torch.cuda.synchronize()
+    rows = frame[H - (y0 + 64):H - y0]
+    assert torch.equal(rows.view(torch.int32), strip.view(torch.int32))
+    assert bool(torch.isfinite(frame).all()) and float(rows.max()) > 0.05 and float(frame.mean()) > 0.005
+
+
 @pytest.mark.parametrize("name", ["monkey", "teapot"])
 def test_sah_binned_tree(orc, scenes, gpu, name):
     """extra.enableBvhSahBinning (reference src/bounding_volume_hierarchy.cpp:96-178): a different tree, same
