@@ -268,8 +268,10 @@ int srt_selftest_division(srt_device* dev, uint32_t seed, uint64_t n, uint64_t* 
  * records (four 16-byte loads per lane, the shape of a node visit) drawn uniformly from the first window_bytes of
  * the uploaded node array followed by the triangle stream, with no arithmetic in between; 0 or a window beyond
  * the records means all of them.  A window of one or two MiB stays in every XCD's L2 (the L2 gather ceiling the
- * traversal kernels are priced against); the full window shows what a walk without any locality would get. */
-int srt_probe_gather(srt_device* dev, srt_scene* scene, uint64_t window_bytes, uint32_t loads_per_lane,
+ * traversal kernels are priced against); the full window shows what a walk without any locality would get.
+ * quad = 0: every lane fetches a record of its own (four loads of 16 bytes); quad = 1: the four lanes of a quad
+ * fetch one record with one load instruction (64 contiguous bytes), the way the shadow walk fetches nodes. */
+int srt_probe_gather(srt_device* dev, srt_scene* scene, uint64_t window_bytes, uint32_t loads_per_lane, uint32_t quad,
                      double* gbytes_per_s, uint64_t* window_used);
 
 #ifdef __cplusplus

@@ -141,7 +141,7 @@ def host():
     L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
-    L.srth_probe_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.srth_probe_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.srth_read_kernel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
     L.srth_kernel_times.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int]
     L.srth_synchronize.argtypes = [C.c_void_p, C.c_void_p]
@@ -415,10 +415,11 @@ class Bvh:
     def synchronize(self, stream=None):
         _check(host().srth_synchronize(self.h, stream))
 
-    def probe_gather(self, window_bytes=0, loads_per_lane=256):
-        """GB/s of 64-byte record gathers over the first window_bytes of the node + triangle records (0: all)."""
+    def probe_gather(self, window_bytes=0, loads_per_lane=256, quad=False):
+        """GB/s of 64-byte record gathers over the first window_bytes of the node + triangle records (0: all); quad:
+        four lanes fetch one record together instead of every lane its own."""
         gbs, used = C.c_double(), C.c_uint64()
-        _check(host().srth_probe_gather(self.h, int(window_bytes), int(loads_per_lane), C.byref(gbs), C.byref(used)))
+        _check(host().srth_probe_gather(self.h, int(window_bytes), int(loads_per_lane), int(bool(quad)), C.byref(gbs), C.byref(used)))
         return float(gbs.value), int(used.value)
 
 

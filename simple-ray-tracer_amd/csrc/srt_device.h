@@ -104,6 +104,9 @@ SRT_DI float refined_rcp(float d)
 }
 SRT_DI float div_by(float x, float d, float r1)
 {
+#ifdef SRT_EXPERIMENT_INEXACT_DIV
+    return x * r1; /* timing experiment only: not the reference's quotient */
+#endif
     float q = x * r1;
     float s = __builtin_fmaf(-d, q, x);
     q = __builtin_fmaf(s, r1, q);
@@ -181,6 +184,30 @@ SRT_DI bool tri_test(const float4* __restrict__ rec, f3 o, f3 d, float& T)
         return false;
     T = nt;
     return true;
+}
+
+/* The two halves of tri_test, for callers that test several triangles of a leaf side by side.
+ * tri_plane: intersectRayWithPlane up to, not including, the comparison with the ray's t (reference
+ * src/intersect.cpp:28-43): false when the ray is parallel to the plane, starts on it or meets it behind its origin. */
+SRT_DI bool tri_plane(const float4 q0, f3 o, f3 d, float& nt)
+{
+    const f3 n = xyz(q0);
+    const float dn = dot3(d, n);
+    const float on = dot3(o, n);
+    nt = (q0.w - on) / dn;
+    return !(dn == 0.0f || on == q0.w) && !(nt < 0);
+}
+/* pointInTriangle for p = o + d * nt on the record's remaining five quarters (reference src/intersect.cpp:13-26) */
+SRT_DI bool tri_inside(const float4* __restrict__ rec, f3 o, f3 d, float nt)
+{
+    const f3 p = o + d * nt;
+    const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+    const f3 v0 = xyz(q1), v1 = xyz(q2), v2 = mk3(q3.x, q3.y, q3.z);
+    const f3 c0 = mk3(q3.w, q4.x, q4.y), c1 = mk3(q4.z, q4.w, q5.x), c2 = mk3(q5.y, q5.z, q5.w);
+    const bool s0 = dot3(cross3(v2 - v1, p - v1), c0) >= 0;
+    const bool s1 = dot3(cross3(v2 - v0, p - v0), c1) >= 0;
+    const bool s2 = dot3(cross3(v1 - v0, p - v0), c2) >= 0;
+    return s0 & s1 & s2;
 }
 
 /* computeBarycentricCoord, reference src/interpolate.cpp:4-15 */

@@ -669,6 +669,22 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
     path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
 }
 
+/* Launch shape of the shadow kernel.  The kernel is bound by the rate at which a compute unit's vector memory path
+ * takes per-lane 16-byte loads (measured with srt_probe_gather: about 1.4 per cycle and compute unit whichever cache
+ * level answers; the walk sustains 1.07), so one option keeps the head of the node array in LDS next to the
+ * stacks: with SRT_SHADOW_LDS_NODES > 0 the first that many records (top levels, if the host stored them breadth
+ * first) are read with ds_read_b128 instead.  Measured on the 18-level stand-in (dragon frame's shadow launch,
+ * 199.1 ms without): 768-thread blocks + 255 nodes (33 % of all node visits) 200.4 ms, 512 + 127 nodes 202.4 ms,
+ * 1024 + 1023 nodes (44 % of visits, but 4 waves per SIMD) 225.5 ms: a wave's lanes are rarely all inside the
+ * cached levels, so both fetch paths run in most steps and their waits add up, which costs what the saved loads
+ * gain (the same kernel with the option compiled in but no node cached: 208.4 ms).  Hence off by default. */
+#ifndef SRT_SHADOW_BLOCK
+#define SRT_SHADOW_BLOCK 256
+#endif
+#ifndef SRT_SHADOW_LDS_NODES
+#define SRT_SHADOW_LDS_NODES 0
+#endif
+
 /* ---- shadow queries: a walk with four-byte stack entries.
  * Until a shadow query accepts its first hit, C is FLT_MAX: no pop test can skip a pending sibling, and the
  * value the general walk keeps beside each sibling is never looked at.  An accepted hit below 0.99 answers the
@@ -726,7 +742,7 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
             const bool pushL = lval < C && (lpass || !CULL);
             const bool pushR = rval < C && (rpass || !CULL);
             if (pushL && pushR) {
-                stk[sp * SRT_BLOCK] = cur;
+                stk[sp * SRT_SHADOW_BLOCK] = cur;
                 ++sp;
             }
             if (pushR) {
@@ -741,7 +757,7 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
         bool found = false;
         while (sp > 0 && !found) {
             --sp;
-            const float4* nd = sc.nodes + 4ull * stk[sp * SRT_BLOCK];
+            const float4* nd = sc.nodes + 4ull * stk[sp * SRT_SHADOW_BLOCK];
             const float4 a = nd[0], b = nd[1];
             const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
             float lval;
@@ -765,21 +781,27 @@ SRT_DI bool swalk_pop(Walk& w, const uint32_t* stk)
     if (w.sp == 0)
         return false;
     --w.sp;
-    w.cur = stk[w.sp * SRT_BLOCK];
+    w.cur = stk[w.sp * SRT_SHADOW_BLOCK];
     return true;
 }
 
 /* walk_inner with t = 1 and C = FLT_MAX: every value of a box in the fast ranges is finite, so the push test
  * `value < C` holds and a child is entered when its box passes (or always, without miss culling). */
 template <bool CULL, bool COUNT>
-SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
+SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st, const float4* lds_nodes, uint32_t n_lds)
 {
     if (COUNT) {
         st.inner += 1;
         st.box += 2;
     }
-    const float4* nd = sc.nodes + 4ull * w.cur;
-    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    float4 a, b, c, e;
+    if (w.cur < n_lds) {
+        const float4* nd = lds_nodes + 4u * w.cur;
+        a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    } else {
+        const float4* nd = sc.nodes + 4ull * w.cur;
+        a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    }
     const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
     const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
     const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
@@ -788,7 +810,7 @@ SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
     const bool pushL = slab_test_fast(llo, lhi, w.o, w.d, w.rr, 1.0f, lval, lin) || !CULL;
     const bool pushR = slab_test_fast(rlo, rhi, w.o, w.d, w.rr, 1.0f, rval, rin) || !CULL;
     if (pushL && pushR) {
-        stk[w.sp * SRT_BLOCK] = left;
+        stk[w.sp * SRT_SHADOW_BLOCK] = left;
         ++w.sp;
         w.cur = right;
     } else if (pushR) {
@@ -808,12 +830,39 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
     const uint32_t cnt = (w.cur >> 24) & 0x7Fu;
     float T = 1.0f;
     bool hit = false;
+#ifdef SRT_LEAF_SERIAL
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
         if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, T))
             hit = true;
     }
+#else
+    /* Two triangles at a time: both plane quarters are fetched together, and so are the remaining quarters of those
+     * whose plane is met within the ray's t, so a pair costs two waits instead of four.  The second triangle is then
+     * accepted against the t the first one left, as when they are tested one after the other. */
+    for (uint32_t k = 0; k < cnt; k += 2) {
+        const float4* r0 = sc.tris + 6ull * (first + k);
+        const bool two = k + 1 < cnt;
+        const float4* r1 = two ? r0 + 6 : r0;
+        const float4 a0 = r0[0], a1 = r1[0];
+        if (COUNT)
+            st.tri += two ? 2 : 1;
+        float nt0, nt1;
+        const bool c0 = tri_plane(a0, w.o, w.d, nt0) && nt0 <= T;
+        const bool c1 = two && tri_plane(a1, w.o, w.d, nt1) && nt1 <= T;
+        bool in0 = false, in1 = false;
+        if (c0 | c1) {
+            /* one block without branches: the ten quarters are requested together */
+            const bool i0 = tri_inside(r0, w.o, w.d, nt0), i1 = tri_inside(r1, w.o, w.d, nt1);
+            in0 = c0 & i0, in1 = c1 & i1;
+        }
+        if (in0)
+            T = nt0, hit = true;
+        if (in1 && nt1 <= T)
+            T = nt1, hit = true;
+    }
+#endif
     if (hit) {
         w.alive = false;
         return T < 0.99f ? 1 : 2;
@@ -832,15 +881,22 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
  * going to consecutive idle lanes, so its lanes keep working on neighbouring samples of the same few hits
  * (same origin, nearby targets on the light). */
 #ifndef SRT_SHADOW_WAVES
-#define SRT_SHADOW_WAVES 6 /* waves per SIMD the register allocation aims at (dragon frame's shadow launch: 5 waves 208 ms, 6: 199, 7: 204) */
+#define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 6) /* waves per SIMD the register allocation aims at */
 #endif
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
+__global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
                                                               const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt,
-                                                              unsigned long long* next_chunk)
+                                                              unsigned long long* next_chunk, uint32_t n_lds)
 {
-    extern __shared__ uint32_t lds_stack4[];
-    uint32_t* stk = lds_stack4 + threadIdx.x;
+    /* LDS: the first n_lds node records, then the per-lane stacks */
+    if (SRT_SHADOW_LDS_NODES == 0)
+        n_lds = 0; /* known at compile time: the LDS branch of the node fetch disappears */
+    extern __shared__ float4 lds_shadow[];
+    const float4* lds_nodes = lds_shadow;
+    for (uint32_t i = threadIdx.x; i < 4u * n_lds; i += SRT_SHADOW_BLOCK)
+        lds_shadow[i] = sc.nodes[i];
+    __syncthreads();
+    uint32_t* stk = (uint32_t*)(lds_shadow + 4u * n_lds) + threadIdx.x;
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShadow = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -849,14 +905,14 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(Sc
      * further one is drawn from a counter all waves share (one atomic per chunk), so waves that happen to get
      * long queries simply draw fewer chunks: with a fixed stride instead, the slowest wave's share decided the
      * launch time (measured 220 -> 200 ms on the dragon frame). */
-    const unsigned long long first_shared = (unsigned long long)gridDim.x * SRT_BLOCK;
+    const unsigned long long first_shared = (unsigned long long)gridDim.x * SRT_SHADOW_BLOCK;
     auto grab = [&]() {
         unsigned long long base = 0;
         if (lane == 0)
             base = atomicAdd(next_chunk, 64ull);
         return first_shared + (unsigned long long)__shfl((long long)base, 0, 64);
     };
-    unsigned long long chunk = (unsigned long long)blockIdx.x * SRT_BLOCK + (threadIdx.x & ~63u); /* wave-uniform */
+    unsigned long long chunk = (unsigned long long)blockIdx.x * SRT_SHADOW_BLOCK + (threadIdx.x & ~63u); /* wave-uniform */
     bool dry = false;                                                                              /* the items have run out */
     uint32_t used = 0; /* items taken from the current chunk */
     Walk w;
@@ -939,7 +995,7 @@ __global__ __launch_bounds__(SRT_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(Sc
             if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
                 st.wave_inner += 1;
             if (atInner)
-                swalk_inner<CULL, COUNT>(sc, w, stk, st);
+                swalk_inner<CULL, COUNT>(sc, w, stk, st, lds_nodes, n_lds);
         } else {
             if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
                 st.wave_leaf += 1;
@@ -1162,6 +1218,10 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_selftest_division(uint32_t seed, 
 __global__ __launch_bounds__(SRT_BLOCK) void k_probe_gather(const float4* __restrict__ nodes, uint32_t n_nodes64, const float4* __restrict__ tris,
                                                               uint32_t n_tris64, uint32_t loads, uint32_t seed, float* sink)
 {
+#ifdef SRT_EXPERIMENT_PROBE_LANES
+    if ((threadIdx.x & 63u) % SRT_EXPERIMENT_PROBE_LANES != 0)
+        return; /* experiment: only every n-th lane of a wave fetches */
+#endif
     const uint32_t tid = blockIdx.x * SRT_BLOCK + threadIdx.x;
     const uint32_t n = n_nodes64 + n_tris64;
     float acc = 0.0f;
@@ -1183,6 +1243,37 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_probe_gather(const float4* __rest
     }
     if (acc == 12345.678f)
         sink[0] = acc; /* keeps the loads alive; practically never taken */
+}
+
+/* The same records fetched the other way round: the four lanes of a quad read the four quarters of ONE record with
+ * one instruction (64 contiguous bytes), four instructions cover the quad's four records. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_probe_gather_quad(const float4* __restrict__ nodes, uint32_t n_nodes64, const float4* __restrict__ tris,
+                                                                   uint32_t n_tris64, uint32_t loads, uint32_t seed, float* sink)
+{
+    const uint32_t tid = blockIdx.x * SRT_BLOCK + threadIdx.x;
+    const uint32_t n = n_nodes64 + n_tris64;
+    const uint32_t q = threadIdx.x & 3u;
+    float acc = 0.0f;
+    uint32_t h = mix32(seed, tid);
+    for (uint32_t it = 0; it < loads; it += 8) {
+        float4 r[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            h = h * 1664525u + 1013904223u;
+            const uint32_t mine = (uint32_t)(((unsigned long long)(h ^ (h >> 15)) * n) >> 32);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const uint32_t idx = (uint32_t)__shfl((int)mine, (int)((threadIdx.x & 60u) + sidx), 64);
+                const float4* rec = idx < n_nodes64 ? nodes + 4ull * idx : tris + 4ull * (idx - n_nodes64);
+                r[u][sidx] = rec[q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc += (r[u][0].x + r[u][1].y) + (r[u][2].z + r[u][3].w);
+    }
+    if (acc == 12345.678f)
+        sink[0] = acc;
 }
 
 /* ------------------------------------------------------------------------------------------ host side */
@@ -1589,13 +1680,16 @@ void srt_scene_destroy(srt_scene* s)
 /* Stack capacity: at most one pending left sibling per inner level. */
 static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + SRT_STACK_SLACK; }
 static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
-static size_t shadow_stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint32_t); }
+static uint32_t shadow_lds_nodes(const srt_scene* s) { return s->view.n_nodes < SRT_SHADOW_LDS_NODES ? s->view.n_nodes : SRT_SHADOW_LDS_NODES; }
+static size_t shadow_lds_bytes(const srt_scene* s) { return (size_t)shadow_lds_nodes(s) * 64 + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
 
 template <typename K>
-static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid)
+static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid, int block = SRT_BLOCK)
 {
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SRT_BLOCK, lds));
+    if (lds > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds));
     if (per_cu < 1)
         return fail(SRT_ERR_INVALID, "kernel does not fit a compute unit with %zu bytes of LDS", lds);
     *grid = per_cu * d->n_cu;
@@ -1658,7 +1752,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     if (need < g_primary) g_primary = need;
     if (need < g_secondary) g_secondary = need;
     if (need < g_shade) g_shade = need;
-    const unsigned long long need_shadow = ((unsigned long long)n * sph + SRT_BLOCK - 1) / SRT_BLOCK;
+    const unsigned long long need_shadow = ((unsigned long long)n * sph + SRT_SHADOW_BLOCK - 1) / SRT_SHADOW_BLOCK;
     if (need_shadow < (unsigned long long)g_shadow) g_shadow = (int)need_shadow;
 
     HitQ hq = wk.hq;
@@ -1678,8 +1772,8 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         float4* nxt = wk.path[(depth + 1) & 1];
         if (sph) {
             mark(d, st, 4, timing);
-            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_BLOCK), shadow_stack_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
-                vis, sph, d->counters + 4, wk.chunk_counters + depth);
+            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
+                vis, sph, d->counters + 4, wk.chunk_counters + depth, shadow_lds_nodes(sc));
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
@@ -1731,7 +1825,7 @@ static int fill_grids(srt_device* d, srt_scene* sc)
     Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
     int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, stack_bytes(sc), &g.primary);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, stack_bytes(sc), &g.secondary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_stack_bytes(sc), &g.shadow);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_lds_bytes(sc), &g.shadow, SRT_SHADOW_BLOCK);
     if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g.shade);
     return rc;
 }
@@ -2024,7 +2118,8 @@ int srt_selftest_division(srt_device* d, uint32_t seed, uint64_t n, uint64_t* mi
     return SRT_OK;
 }
 
-int srt_probe_gather(srt_device* d, srt_scene* sc, uint64_t window_bytes, uint32_t loads_per_lane, double* gbytes_per_s, uint64_t* window_used)
+int srt_probe_gather(srt_device* d, srt_scene* sc, uint64_t window_bytes, uint32_t loads_per_lane, uint32_t quad, double* gbytes_per_s,
+                     uint64_t* window_used)
 {
     if (!d || !sc || !gbytes_per_s || sc->dev != d)
         return fail(SRT_ERR_INVALID, "srt_probe_gather: bad argument");
@@ -2046,9 +2141,10 @@ int srt_probe_gather(srt_device* d, srt_scene* sc, uint64_t window_bytes, uint32
     const int grid = d->n_cu * 8;
     float* sink = (float*)(d->counters + SRT_FAMILIES);
     /* one untimed pass brings the window into the caches it fits */
-    hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 1u, sink);
+    auto kern = quad ? k_probe_gather_quad : k_probe_gather;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 1u, sink);
     hipError_t e = hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(k_probe_gather, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 2u, sink);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SRT_BLOCK), 0, 0, sc->view.nodes, n_nodes64, sc->view.tris, n_tris64, loads_per_lane, 2u, sink);
     if (e == hipSuccess) e = hipEventRecord(e1, 0);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0;

@@ -462,7 +462,10 @@ BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     , m_gpu(currentDevice())
 {
     srt_device* dev = deviceFor(m_gpu);
-    const FlatScene flat = m_impl->flatten(0);
+    /* Depth-first node order.  SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead, for builds
+     * of the back end that keep the head of the node array in LDS (SRT_SHADOW_LDS_NODES, off by default). */
+    const char* lv = std::getenv("SRT_EXPERIMENT_BFS_LEVELS");
+    const FlatScene flat = m_impl->flatten(lv ? std::atoi(lv) : 0);
     const srt_scene_desc d = flat.desc();
     if (srt_scene_upload(dev, &d, &m_dev) != SRT_OK) {
         delete m_impl;

@@ -307,9 +307,9 @@ int srth_render_noalloc(const srth_bvh* b, const srt_render_params* params, cons
     return 0;
 }
 
-int srth_probe_gather(const srth_bvh* b, uint64_t window_bytes, uint32_t loads_per_lane, double* gbytes_per_s, uint64_t* window_used)
+int srth_probe_gather(const srth_bvh* b, uint64_t window_bytes, uint32_t loads_per_lane, uint32_t quad, double* gbytes_per_s, uint64_t* window_used)
 {
-    if (srt_probe_gather(b->bvh->device(), b->bvh->deviceScene(), window_bytes, loads_per_lane, gbytes_per_s, window_used) != SRT_OK) {
+    if (srt_probe_gather(b->bvh->device(), b->bvh->deviceScene(), window_bytes, loads_per_lane, quad, gbytes_per_s, window_used) != SRT_OK) {
         g_err = srt_last_error();
         return -1;
     }
