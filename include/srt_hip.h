@@ -39,6 +39,15 @@ extern "C" {
  * sends the ray on through the surface, so a sample's rays form a binary tree; the hits of its deepest level
  * (max_depth) then contribute nothing, as in the reference. */
 #define SRT_F_TRANSPARENCY (1u << 10)
+/* extra.enableMotionBlur / enableDepthOfField (reference src/render.cpp:152-178,218-223): srt_lens.samples rays per
+ * pixel through a jittered origin; as in the reference, multisampling takes precedence over motion blur and
+ * motion blur over depth of field.  The reference draws the jitter from libc rand(); here it comes from the
+ * counter-based generator the soft-shadow samplers use (seed in srt_render_params). */
+#define SRT_F_MOTION_BLUR (1u << 11)
+#define SRT_F_DEPTH_OF_FIELD (1u << 12)
+/* extra.enableEnvironmentMapping (reference src/render.cpp:40-81,141-147): a ray that hits nothing returns the
+ * texel of the scene's environment image its exit point from the box [-64, 64]^3 maps to. */
+#define SRT_F_ENVIRONMENT (1u << 13)
 /* Traversal policy.  0: the reference's exact visiting rule (a shadow ray walks the whole tree until its
  * first hit).  1: additionally skip every box whose slab test fails; same result up to rounding of
  * hit points, orders of magnitude less work.  The host mirror sets it by default. */
@@ -137,6 +146,8 @@ typedef struct srt_scene_desc {
     uint64_t n_texels;
     const srt_light* lights;
     uint32_t n_lights;
+    uint32_t environment; /* 0: none; k: textures[k - 1] is the cube-map cross image of SRT_F_ENVIRONMENT (the reference
+                             loads data/cube_map.jpg into a global, src/render.cpp:38) */
 } srt_scene_desc;
 
 /* Camera constants: Trackball::position / generateRay, reference framework/src/trackball.cpp:71-74,101-110
@@ -170,6 +181,15 @@ typedef struct srt_counters {
     uint64_t wave_leaf_steps;  /* inner_visits / (64 * wave_inner_steps); likewise for leaves */
 } srt_counters;
 
+/* The Scene's motion-blur and depth-of-field variables (reference src/scene.h:32-40). */
+typedef struct srt_lens {
+    int32_t samples;       /* MB_samples or DOF_samples, whichever mode is active; 0 renders black, as in the reference */
+    float time0, time1;    /* motion blur */
+    float direction[3];    /* directionVector */
+    float focal_length;    /* depth of field; the reference keeps it as an int and converts */
+    float aperture;
+} srt_lens;
+
 typedef struct srt_render_params {
     srt_camera camera;
     uint32_t features;
@@ -178,6 +198,7 @@ typedef struct srt_render_params {
     uint32_t seed;                /* soft-shadow sampler */
     int32_t rect[4];              /* x0, y0, x1, y1: pixels [x0,x1) x [y0,y1), y counted upwards as in render.cpp:187-188 */
     uint32_t flags;               /* SRT_RENDER_* */
+    srt_lens lens;                /* read with SRT_F_MOTION_BLUR / SRT_F_DEPTH_OF_FIELD only */
 } srt_render_params;
 
 #define SRT_RENDER_STATS (1u << 0)  /* also count node visits / triangle tests (slower kernels) */

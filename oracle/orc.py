@@ -22,6 +22,9 @@ F_ACCEL = 1 << 6
 F_MULTISAMPLE = 1 << 7
 F_SAH = 1 << 8
 F_TRANSPARENCY = 1 << 10
+F_MOTION_BLUR = 1 << 11
+F_DEPTH_OF_FIELD = 1 << 12
+F_ENVIRONMENT = 1 << 13
 F_MISS_CULL = 1 << 16
 
 LIGHT_STRIDE = 22
@@ -60,6 +63,30 @@ class Camera(C.Structure):
         ("width", C.c_int32),
         ("height", C.c_int32),
     ]
+
+
+class Extras(C.Structure):
+    _fields_ = [("samples", C.c_int32), ("time0", C.c_float), ("time1", C.c_float), ("direction", C.c_float * 3),
+                ("focal_length", C.c_float), ("aperture", C.c_float), ("env_texels", _f32p), ("env_w", C.c_int32),
+                ("env_h", C.c_int32)]
+
+
+def make_extras(lens=None, environment=None):
+    """lens: dict(samples, time0, time1, direction, focal_length, aperture); environment: float RGB (H, W, 3).
+    Returns (struct, objects to keep alive)."""
+    e = Extras()
+    keep = []
+    if lens:
+        e.samples = int(lens.get("samples", 0))
+        e.time0, e.time1 = float(lens.get("time0", 0.0)), float(lens.get("time1", 0.0))
+        e.direction[:] = [float(x) for x in lens.get("direction", (0, 0, 0))]
+        e.focal_length, e.aperture = float(lens.get("focal_length", 0)), float(lens.get("aperture", 0.0))
+    if environment is not None:
+        env = np.ascontiguousarray(environment, np.float32)
+        e.env_texels = _ptr(env, _f32p)
+        e.env_h, e.env_w = env.shape[0], env.shape[1]
+        keep.append(env)
+    return e, keep
 
 
 class Counters(C.Structure):
@@ -107,6 +134,8 @@ def lib():
                                             C.POINTER(Counters)]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_uint32, _i32p, _f32p, _i32p, _i32p, _f32p, C.c_int32, C.POINTER(Counters)]
+        L.orc_render_ex.argtypes = L.orc_render.argtypes + [C.POINTER(Extras)]
+        L.orc_final_color_batch_ex.argtypes = L.orc_final_color_batch.argtypes + [C.POINTER(Extras)]
         L.orc_camera_make.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, _f32p, _f32p, C.c_int32, C.c_int32]
         L.orc_camera_ray.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, _f32p]
         L.orc_ray_triangle.argtypes = [_f32p, _f32p, _f32p, _f32p]
@@ -261,15 +290,17 @@ class Bvh:
         lib().orc_intersect_batch(self.h, _ptr(rays, _f32p), len(rays), features, out.ctypes.data, C.byref(cnt))
         return out, cnt.as_dict()
 
-    def final_color(self, rays7, features, max_depth=5, seed=0):
+    def final_color(self, rays7, features, max_depth=5, seed=0, environment=None):
         rays = np.ascontiguousarray(rays7, np.float32)
         rgb = np.zeros((len(rays), 3), np.float32)
         cnt = Counters()
-        lib().orc_final_color_batch(self.h, _ptr(rays, _f32p), len(rays), features, max_depth, seed,
-                                    _ptr(rgb, _f32p), C.byref(cnt))
+        ex, keep = make_extras(None, environment)
+        lib().orc_final_color_batch_ex(self.h, _ptr(rays, _f32p), len(rays), features, max_depth, seed,
+                                       _ptr(rgb, _f32p), C.byref(cnt), C.byref(ex))
         return rgb, cnt.as_dict()
 
-    def render(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, threads=0, primary=True):
+    def render(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, threads=0, primary=True, lens=None,
+               environment=None):
         W, H = cam.width, cam.height
         rgb = np.zeros((H, W, 3), np.float32)
         pm = np.full((H, W), -1, np.int32)
@@ -277,9 +308,10 @@ class Bvh:
         tt = np.zeros((H, W), np.float32)
         cnt = Counters()
         r = None if rect is None else _ptr(np.array(rect, np.int32), _i32p)
-        lib().orc_render(self.h, C.byref(cam), features, nsx, nsy, max_depth, seed, r, _ptr(rgb, _f32p),
-                         _ptr(pm, _i32p) if primary else None, _ptr(pt, _i32p) if primary else None,
-                         _ptr(tt, _f32p) if primary else None, threads, C.byref(cnt))
+        ex, keep = make_extras(lens, environment)
+        lib().orc_render_ex(self.h, C.byref(cam), features, nsx, nsy, max_depth, seed, r, _ptr(rgb, _f32p),
+                            _ptr(pm, _i32p) if primary else None, _ptr(pt, _i32p) if primary else None,
+                            _ptr(tt, _f32p) if primary else None, threads, C.byref(cnt), C.byref(ex))
         return {"rgb": rgb, "mesh": pm, "tri": pt, "t": tt, "counters": cnt.as_dict()}
 
 

@@ -372,6 +372,7 @@ struct Ctx {
     int max_depth;
     uint32_t seed;
     orc_counters cnt {};
+    const orc_extras* ex = nullptr;
 };
 
 /* intersectWithLeafTriangle + shoudlBeReverted, src/bounding_volume_hierarchy.cpp:262-303 */
@@ -557,7 +558,52 @@ V3 light_contribution(Ctx& c, const Ray& ray, const HitInfo& hit, uint32_t path,
     return res;
 }
 
-/* getFinalColor, src/render.cpp:83-150 (environment map / debug branches left out) */
+/* getEnvironmentTexelCoords and the miss branch of getFinalColor, src/render.cpp:40-81,141-147 */
+V3 environment_color(Ctx& c, Ray ray)
+{
+    if (!c.ex || !c.ex->env_texels)
+        return { 0, 0, 0 };
+    float val;
+    if (!slab({ { -64, -64, -64 }, { 64, 64, 64 } }, ray, val))
+        return { 0, 0, 0 };
+    ray.t = val;
+    const V3 p = (ray.o + ray.d * ray.t) / 64.0f;
+    const float absX = std::fabs(p.x), absY = std::fabs(p.y), absZ = std::fabs(p.z);
+    V2 center = { -1, -1 }, shift = { -1, -1 };
+    if (absX >= absY && absX >= absZ) {
+        if (p.x > 0) {
+            center = { 2.5f / 4, 1.5f / 3 };
+            shift = { -p.z / 8, p.y / 6 };
+        } else {
+            center = { 0.5f / 4, 1.5f / 3 };
+            shift = { p.z / 8, p.y / 6 };
+        }
+    }
+    if (absY >= absX && absY >= absZ) {
+        if (p.y > 0) {
+            center = { 1.5f / 4, 2.5f / 3 };
+            shift = { p.x / 8, -p.z / 6 };
+        } else {
+            center = { 1.5f / 4, 0.5f / 3 };
+            shift = { p.x / 8, p.z / 6 };
+        }
+    }
+    if (absZ >= absX && absZ >= absY) {
+        if (p.z > 0) {
+            center = { 1.5f / 4, 1.5f / 3 };
+            shift = { p.x / 8, p.y / 6 };
+        } else {
+            center = { 3.5f / 4, 1.5f / 3 };
+            shift = { -p.x / 8, p.y / 6 };
+        }
+    }
+    V2 ans = { center.x + shift.x, center.y + shift.y };
+    if (!(0 <= ans.x && ans.x <= 1 && 0 <= ans.y && ans.y <= 1))
+        ans = { 0, 0 };
+    return texel(c.ex->env_texels, c.ex->env_w, c.ex->env_h, ans);
+}
+
+/* getFinalColor, src/render.cpp:83-150 (debug branches left out) */
 V3 final_color(Ctx& c, Ray ray, int depth, uint32_t path, orc_hit* primary)
 {
     HitInfo hit;
@@ -574,7 +620,7 @@ V3 final_color(Ctx& c, Ray ray, int depth, uint32_t path, orc_hit* primary)
         primary->kd[0] = hit.material.kd.x, primary->kd[1] = hit.material.kd.y, primary->kd[2] = hit.material.kd.z;
     }
     if (!h)
-        return { 0, 0, 0 };
+        return (c.features & ORC_F_ENVIRONMENT) ? environment_color(c, ray) : V3 { 0, 0, 0 };
     c.cnt.shaded_hits += 1;
     V3 Lo = light_contribution(c, ray, hit, path, (uint32_t)depth);
     if (c.features & ORC_F_RECURSIVE) {
@@ -777,7 +823,14 @@ void orc_texel(const float* texels, int32_t w, int32_t h, float u, float v, floa
 void orc_final_color_batch(const orc_bvh* bvh, const float* rays7, int64_t n, uint32_t features, int32_t max_depth,
                            uint32_t seed, float* rgb, orc_counters* counters)
 {
+    orc_final_color_batch_ex(bvh, rays7, n, features, max_depth, seed, rgb, counters, nullptr);
+}
+
+void orc_final_color_batch_ex(const orc_bvh* bvh, const float* rays7, int64_t n, uint32_t features, int32_t max_depth,
+                              uint32_t seed, float* rgb, orc_counters* counters, const orc_extras* extras)
+{
     Ctx c { *bvh, features, max_depth, seed };
+    c.ex = extras;
     for (int64_t i = 0; i < n; ++i) {
         const float* r = rays7 + 7 * i;
         Ray ray = { v3(r), v3(r + 3), r[6] };
@@ -794,7 +847,18 @@ void orc_render(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, in
                 int32_t max_depth, uint32_t seed, const int32_t rect[4], float* rgb, int32_t* prim_mesh,
                 int32_t* prim_tri, float* prim_t, int32_t n_threads, orc_counters* counters)
 {
+    orc_render_ex(bvh, cam, features, nsx, nsy, max_depth, seed, rect, rgb, prim_mesh, prim_tri, prim_t, n_threads, counters, nullptr);
+}
+
+void orc_render_ex(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int32_t nsx, int32_t nsy,
+                   int32_t max_depth, uint32_t seed, const int32_t rect[4], float* rgb, int32_t* prim_mesh,
+                   int32_t* prim_tri, float* prim_t, int32_t n_threads, orc_counters* counters, const orc_extras* extras)
+{
     const int W = cam->width, H = cam->height;
+    /* the else-if chain of src/render.cpp:196-227 */
+    const int lens_mode = (features & ORC_F_MULTISAMPLE) ? 0 : ((features & ORC_F_MOTION_BLUR) ? 1 : ((features & ORC_F_DEPTH_OF_FIELD) ? 2 : 0));
+    const orc_extras none {};
+    const orc_extras& ex = extras ? *extras : none;
     const int x0 = rect ? rect[0] : 0, y0 = rect ? rect[1] : 0, x1 = rect ? rect[2] : W, y1 = rect ? rect[3] : H;
     const bool ms = (features & ORC_F_MULTISAMPLE) != 0;
     if (!ms)
@@ -807,6 +871,7 @@ void orc_render(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, in
 #endif
     {
         Ctx c { *bvh, features, max_depth, seed };
+        c.ex = extras;
 #ifdef _OPENMP
 #pragma omp for schedule(guided)
 #endif
@@ -829,6 +894,31 @@ void orc_render(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, in
                         }
                     }
                     colour = colour / (float)(nsx * nsy);
+                } else if (lens_mode) {
+                    /* motionBlur / DOF, src/render.cpp:152-178: one camera ray through the pixel, `samples` jittered copies */
+                    const float nx = (float)x / (float)W * 2.0f - 1.0f;
+                    const float ny = (float)y / (float)H * 2.0f - 1.0f;
+                    const Ray cameraRay = camera_ray(*cam, nx, ny);
+                    const int N = ex.samples;
+                    for (int t = 0; t < N; ++t) {
+                        const uint32_t key = pix * (uint32_t)N + (uint32_t)t;
+                        Ray ray = cameraRay;
+                        if (lens_mode == 1) {
+                            const float random = rand01(seed, key, 0xFFFFFFFFu, 0, 0, 0);
+                            const float k = (ex.time0 + random * (ex.time1 - ex.time0)) - ((ex.time1 - ex.time0) / 2);
+                            ray.o = cameraRay.o + normalize(v3(ex.direction)) * k;
+                        } else {
+                            const V3 converge = cameraRay.o + cameraRay.d * ex.focal_length;
+                            const float r1 = -1.0f + 2.0f * rand01(seed, key, 0xFFFFFFFFu, 0, 0, 0);
+                            const float r2 = -1.0f + 2.0f * rand01(seed, key, 0xFFFFFFFFu, 0, 0, 1);
+                            const float r3 = -1.0f + 2.0f * rand01(seed, key, 0xFFFFFFFFu, 0, 0, 2);
+                            ray.o = cameraRay.o + V3 { r1 * ex.aperture, r2 * ex.aperture, r3 * ex.aperture };
+                            ray.d = normalize(converge - ray.o);
+                        }
+                        colour = colour + final_color(c, ray, 0, key, t == 0 ? &prim : nullptr) / (float)N;
+                    }
+                    if (N == 0)
+                        prim.mesh = prim.tri = -1;
                 } else {
                     float nx = (float)x / (float)W * 2.0f - 1.0f;
                     float ny = (float)y / (float)H * 2.0f - 1.0f;

@@ -27,6 +27,9 @@ enum {
     ORC_F_MULTISAMPLE    = 1u << 7,  /* extra.enableMultipleRaysPerPixel */
     ORC_F_SAH            = 1u << 8,  /* extra.enableBvhSahBinning (build only) */
     ORC_F_TRANSPARENCY   = 1u << 10, /* extra.enableTransparency */
+    ORC_F_MOTION_BLUR    = 1u << 11, /* extra.enableMotionBlur */
+    ORC_F_DEPTH_OF_FIELD = 1u << 12, /* extra.enableDepthOfField */
+    ORC_F_ENVIRONMENT    = 1u << 13, /* extra.enableEnvironmentMapping */
     /* traversal policy: 0 = reference-faithful, 1 = additionally cull every box whose slab test fails */
     ORC_F_MISS_CULL      = 1u << 16,
 };
@@ -126,6 +129,28 @@ void orc_render(const orc_bvh*, const orc_camera* cam, uint32_t features, int32_
                 int32_t max_depth, uint32_t seed, const int32_t rect[4], float* rgb,
                 int32_t* prim_mesh, int32_t* prim_tri, float* prim_t, int32_t n_threads,
                 orc_counters* counters);
+
+/* The Scene's motion-blur / depth-of-field variables (reference src/scene.h:32-40) and the environment image
+ * (the reference's global envImage, src/render.cpp:38), for orc_render_ex. */
+typedef struct {
+    int32_t samples;       /* MB_samples or DOF_samples, whichever mode is active */
+    float time0, time1;
+    float direction[3];
+    float focal_length;
+    float aperture;
+    const float* env_texels; /* RGB float, row-major, top row first; NULL for none */
+    int32_t env_w, env_h;
+} orc_extras;
+
+/* orc_render plus the branches of reference src/render.cpp:135-178,218-223: environment map on misses, motion blur
+ * and depth of field (jitter from the counter-based generator; the reference uses rand()). */
+void orc_render_ex(const orc_bvh*, const orc_camera* cam, uint32_t features, int32_t nsx, int32_t nsy,
+                   int32_t max_depth, uint32_t seed, const int32_t rect[4], float* rgb,
+                   int32_t* prim_mesh, int32_t* prim_tri, float* prim_t, int32_t n_threads,
+                   orc_counters* counters, const orc_extras* extras);
+/* orc_final_color_batch with an environment image. */
+void orc_final_color_batch_ex(const orc_bvh*, const float* rays7, int64_t n, uint32_t features,
+                              int32_t max_depth, uint32_t seed, float* rgb, orc_counters* counters, const orc_extras* extras);
 
 /* Counter-based uniform sample in [0,1) shared with the device code. */
 float orc_rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim);

@@ -31,6 +31,9 @@ F_ACCEL = 1 << 6
 F_MULTISAMPLE = 1 << 7
 F_SAH = 1 << 8           # host-side build option (extra.enableBvhSahBinning)
 F_TRANSPARENCY = 1 << 10  # extra.enableTransparency
+F_MOTION_BLUR = 1 << 11   # extra.enableMotionBlur (Scene.set_lens)
+F_DEPTH_OF_FIELD = 1 << 12  # extra.enableDepthOfField
+F_ENVIRONMENT = 1 << 13   # extra.enableEnvironmentMapping (Scene.set_environment)
 F_BLOOM = 1 << 9         # host-side pass of the C++ mirror (extra.enableBloomEffect); not a kernel flag
 F_MISS_CULL = 1 << 16    # traversal policy; clear it for the reference's exact visiting rule
 
@@ -53,9 +56,15 @@ class Camera(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class Lens(C.Structure):
+    _fields_ = [("samples", C.c_int32), ("time0", C.c_float), ("time1", C.c_float), ("direction", C.c_float * 3),
+                ("focal_length", C.c_float), ("aperture", C.c_float)]
+
+
 class RenderParams(C.Structure):
     _fields_ = [("camera", Camera), ("features", C.c_uint32), ("samples_x", C.c_int32), ("samples_y", C.c_int32),
-                ("max_depth", C.c_int32), ("seed", C.c_uint32), ("rect", C.c_int32 * 4), ("flags", C.c_uint32)]
+                ("max_depth", C.c_int32), ("seed", C.c_uint32), ("rect", C.c_int32 * 4), ("flags", C.c_uint32),
+                ("lens", Lens)]
 
 
 class Output(C.Structure):
@@ -113,6 +122,10 @@ def host():
     L.srth_scene_add_texture.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p]
     L.srth_scene_add_mesh.argtypes = [C.c_void_p, _f32p, C.c_int, _u32p, C.c_int, _f32p, C.c_int]
     L.srth_scene_add_light.argtypes = [C.c_void_p, _f32p]
+    L.srth_scene_set_environment.argtypes = [C.c_void_p, C.c_int, C.c_int, _f32p]
+    L.srth_scene_load_environment.argtypes = [C.c_void_p, C.c_char_p]
+    L.srth_scene_set_lens.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, _f32p, C.c_int, C.c_float, C.c_int]
+    L.srth_image_load.argtypes = [C.c_char_p, _i32p, _i32p, _f32p]
     L.srth_scene_load_obj.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.srth_scene_load_prebuilt.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
     L.srth_scene_num_meshes.argtypes = [C.c_void_p]
@@ -229,6 +242,20 @@ class Scene:
         s = cls()
         _check(host().srth_scene_load_prebuilt(s.h, int(scene_type), os.fsencode(data_dir)))
         return s
+
+    def set_environment(self, rgb):
+        """Scene::environment: float RGB image (H, W, 3), top row first; set it before building the Bvh."""
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        _check(host().srth_scene_set_environment(self.h, rgb.shape[1], rgb.shape[0], _p(rgb)))
+
+    def load_environment(self, data_dir):
+        """Scene::environment = <data_dir>/cube_map.jpg, the file the reference's environment map is read from."""
+        _check(host().srth_scene_load_environment(self.h, os.fsencode(data_dir)))
+
+    def set_lens(self, mb_samples=0, time0=0.0, time1=0.0, direction=(0, 0, 0), focal_length=0, aperture=0.0, dof_samples=0):
+        """The Scene's motion-blur and depth-of-field variables (used by mirror_render)."""
+        d = np.array(direction, np.float32)
+        _check(host().srth_scene_set_lens(self.h, int(mb_samples), float(time0), float(time1), _p(d), int(focal_length), float(aperture), int(dof_samples)))
 
     def add_light(self, light22):
         _check(host().srth_scene_add_light(self.h, _p(np.ascontiguousarray(light22, np.float32))))
@@ -350,8 +377,14 @@ class Bvh:
         _check(host().srth_final_color(self.h, _p(rays), len(rays), features, max_depth, seed, _p(rgb)))
         return rgb
 
-    def params(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0):
+    def params(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0, lens=None):
+        """lens: dict(samples, time0, time1, direction, focal_length, aperture) for F_MOTION_BLUR / F_DEPTH_OF_FIELD."""
         p = RenderParams()
+        if lens:
+            p.lens.samples = int(lens.get("samples", 0))
+            p.lens.time0, p.lens.time1 = float(lens.get("time0", 0.0)), float(lens.get("time1", 0.0))
+            p.lens.direction[:] = [float(x) for x in lens.get("direction", (0, 0, 0))]
+            p.lens.focal_length, p.lens.aperture = float(lens.get("focal_length", 0)), float(lens.get("aperture", 0.0))
         p.camera = cam
         p.features = features
         p.samples_x, p.samples_y = nsx, nsy
@@ -362,14 +395,14 @@ class Bvh:
         p.flags = flags
         return p
 
-    def render(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0, primary=True):
+    def render(self, cam, features, nsx=1, nsy=1, max_depth=5, seed=0, rect=None, flags=0, primary=True, lens=None):
         """renderRayTracing into host arrays in Screen layout; returns rgb (+ primary hit of sample 0)."""
         W, H = cam.width, cam.height
         rgb = np.zeros((H, W, 3), np.float32)
         pm = np.full((H, W), -1, np.int32)
         pt = np.full((H, W), -1, np.int32)
         tt = np.zeros((H, W), np.float32)
-        p = self.params(cam, features, nsx, nsy, max_depth, seed, rect, flags)
+        p = self.params(cam, features, nsx, nsy, max_depth, seed, rect, flags, lens)
         o = Output()
         o.rgb = rgb.ctypes.data
         if primary:
@@ -496,6 +529,15 @@ def config_describe(toml_text):
 
 
 CLI = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "srt_render")
+
+
+def load_image(path):
+    """Image(path) of the host mirror (PNG, JPEG): float RGB (H, W, 3), top row first, u8 / 255."""
+    w, h = C.c_int32(), C.c_int32()
+    _check(host().srth_image_load(os.fsencode(path), C.byref(w), C.byref(h), None))
+    rgb = np.zeros((h.value, w.value, 3), np.float32)
+    _check(host().srth_image_load(os.fsencode(path), C.byref(w), C.byref(h), _p(rgb)))
+    return rgb
 
 
 def write_bmp(path, rgb):

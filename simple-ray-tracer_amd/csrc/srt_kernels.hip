@@ -60,6 +60,7 @@ struct SceneDev {
     uint32_t n_nodes, n_tris, n_materials, n_textures, n_lights;
     uint32_t root_ref;
     float root_lo[3], root_hi[3];
+    int32_t env_tex;     /* texture index of the environment image, -1 for none */
     uint32_t fast_boxes; /* every box has lower <= upper and coordinates 0 or 2^-40 <= |c| < 2^20: slab_test_fast applies */
     uint64_t n_texels;
 };
@@ -95,6 +96,8 @@ struct RenderDev {
     float* out_t;
     int32_t out_w, out_h, out_x0, out_y0;
     const float* custom_rays; /* when set, sample s is the caller's ray s (7 floats) instead of a camera ray */
+    srt_lens lens;
+    int32_t lens_mode; /* 0: none; 1: motion blur; 2: depth of field (S = lens.samples rays per pixel) */
 };
 
 /* ------------------------------------------------------------------------------------------ traversal */
@@ -550,7 +553,62 @@ SRT_DI bool primary_ray(const RenderDev& rp, uint32_t s, f3& o, f3& d, float& T,
     o = mk3(rp.cam.origin[0], rp.cam.origin[1], rp.cam.origin[2]);
     d = camera_dir(rp.cam, nx, ny);
     T = SRT_FLT_MAX;
+    if (rp.lens_mode) {
+        /* sampler key: the frame-global sample number, in a stream of its own (depth field all ones) */
+        const uint32_t key = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
+        if (rp.lens_mode == 1) {
+            /* motionBlur, reference src/render.cpp:152-161 */
+            const float random = rand01(rp.seed, key, 0xFFFFFFFFu, 0, 0, 0);
+            const float t0 = rp.lens.time0, t1 = rp.lens.time1;
+            const float k = (t0 + random * (t1 - t0)) - ((t1 - t0) / 2);
+            o = o + normalize3(mk3(rp.lens.direction[0], rp.lens.direction[1], rp.lens.direction[2])) * k;
+        } else {
+            /* DOF, reference src/render.cpp:163-178: r in [-1, 1) */
+            const f3 converge = o + d * rp.lens.focal_length;
+            const float r1 = -1.0f + 2.0f * rand01(rp.seed, key, 0xFFFFFFFFu, 0, 0, 0);
+            const float r2 = -1.0f + 2.0f * rand01(rp.seed, key, 0xFFFFFFFFu, 0, 0, 1);
+            const float r3 = -1.0f + 2.0f * rand01(rp.seed, key, 0xFFFFFFFFu, 0, 0, 2);
+            o = o + mk3(r1 * rp.lens.aperture, r2 * rp.lens.aperture, r3 * rp.lens.aperture);
+            d = normalize3(converge - o);
+        }
+    }
     return true;
+}
+
+/* The miss branch of getFinalColor with extra.enableEnvironmentMapping (reference src/render.cpp:40-81,141-147):
+ * where the ray leaves (or enters) the box [-64, 64]^3, mapped onto the cross-shaped cube-map image. */
+SRT_DI f3 environment_color(const SceneDev& sc, f3 o, f3 d, float T)
+{
+    const float lo[3] = { -64.0f, -64.0f, -64.0f }, hi[3] = { 64.0f, 64.0f, 64.0f };
+    float t;
+    bool inside;
+    if (sc.env_tex < 0 || !slab_test(lo, hi, o, d, T, t, inside))
+        return mk3(0, 0, 0);
+    const f3 p = (o + d * t) / 64.0f;
+    const float ax = __builtin_fabsf(p.x), ay = __builtin_fabsf(p.y), az = __builtin_fabsf(p.z);
+    f2 center = { -1.0f, -1.0f }, shift = { -1.0f, -1.0f };
+    if (ax >= ay && ax >= az) {
+        if (p.x > 0)
+            center = { 2.5f / 4, 1.5f / 3 }, shift = { -p.z / 8, p.y / 6 };
+        else
+            center = { 0.5f / 4, 1.5f / 3 }, shift = { p.z / 8, p.y / 6 };
+    }
+    if (ay >= ax && ay >= az) {
+        if (p.y > 0)
+            center = { 1.5f / 4, 2.5f / 3 }, shift = { p.x / 8, -p.z / 6 };
+        else
+            center = { 1.5f / 4, 0.5f / 3 }, shift = { p.x / 8, p.z / 6 };
+    }
+    if (az >= ax && az >= ay) {
+        if (p.z > 0)
+            center = { 1.5f / 4, 1.5f / 3 }, shift = { p.x / 8, p.y / 6 };
+        else
+            center = { 3.5f / 4, 1.5f / 3 }, shift = { -p.x / 8, p.y / 6 };
+    }
+    f2 ans = { center.x + shift.x, center.y + shift.y };
+    if (!(0 <= ans.x && ans.x <= 1 && 0 <= ans.y && ans.y <= 1))
+        ans.x = 0, ans.y = 0;
+    return fetch_texel(sc, sc.env_tex, ans);
 }
 
 /* Appends the lanes with want == true to a queue: one atomic per wave, slots in lane order. */
@@ -570,7 +628,7 @@ SRT_DI uint32_t queue_slot(bool want, uint32_t* count)
 }
 
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, RenderDev rp, HitQ hq, uint32_t* hq_count, DevCounters* cnt)
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, RenderDev rp, HitQ hq, uint32_t* hq_count, DevCounters* cnt, float* acc)
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
@@ -588,6 +646,10 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, Render
         if (active && primary_ray(rp, s, o, d, T, px, py, sub)) {
             nPath += 1;
             hit = bvh_query<CULL, COUNT>(sc, rp.features, o, d, T, tri, stk, st);
+            if (!hit && (rp.features & SRT_F_ENVIRONMENT)) {
+                const f3 e = environment_color(sc, o, d, T);
+                acc[3ull * s] = e.x, acc[3ull * s + 1] = e.y, acc[3ull * s + 2] = e.z;
+            }
             if (sub == 0 && (rp.out_mesh || rp.out_tri || rp.out_t)) {
                 const long long oi = out_index(rp, px, py);
                 int mesh = -1, ti = -1;
@@ -612,7 +674,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, Render
 
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint32_t features, const float4* paths, const uint32_t* n_paths,
-                                                                 HitQ hq, uint32_t* hq_count, DevCounters* cnt)
+                                                                 HitQ hq, uint32_t* hq_count, DevCounters* cnt, float* acc)
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
@@ -630,6 +692,22 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
             const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
             nPath += 1;
             hit = bvh_query<CULL, COUNT>(sc, features, o, d, T, tri, stk, st);
+            if (!hit && (features & SRT_F_ENVIRONMENT)) {
+                /* the environment seen by a reflected / transmitted ray, weighted like a hit's light (k_shade) */
+                const float4 c = paths[3ull * i + 2];
+                const f3 thr = mk3(b.z, b.w, c.x);
+                const f3 e = environment_color(sc, o, d, T);
+                float* a3 = acc + 3ull * __float_as_uint(c.y);
+                if (features & SRT_F_TRANSPARENCY) {
+                    atomicAdd(a3 + 0, thr.x * e.x);
+                    atomicAdd(a3 + 1, thr.y * e.y);
+                    atomicAdd(a3 + 2, thr.z * e.z);
+                } else {
+                    a3[0] = a3[0] + thr.x * e.x;
+                    a3[1] = a3[1] + thr.y * e.y;
+                    a3[2] = a3[2] + thr.z * e.z;
+                }
+            }
         }
         const uint32_t q = queue_slot(hit, hq_count);
         if (hit) {
@@ -1107,7 +1185,13 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float
         const int py = rp.y0 + (int)(p / (uint32_t)rp.tw), px = rp.x0 + (int)(p % (uint32_t)rp.tw);
         f3 c = mk3(0, 0, 0);
         const uint32_t first = rp.custom_rays ? p : pixel_first_sample(rp, (uint32_t)(px - rp.x0), (uint32_t)(py - rp.y0));
-        if (rp.features & SRT_F_MULTISAMPLE) {
+        if (rp.lens_mode) {
+            /* Lo += getFinalColor(...) / samples, reference src/render.cpp:158,175 (black with zero samples) */
+            for (int s = 0; s < rp.lens.samples; ++s) {
+                const float* a = acc + 3ull * (first + (uint32_t)s);
+                c = c + mk3(a[0], a[1], a[2]) / (float)rp.lens.samples;
+            }
+        } else if (rp.features & SRT_F_MULTISAMPLE) {
             for (int s = 0; s < rp.S; ++s) {
                 const float* a = acc + 3ull * (first + (uint32_t)s);
                 c = c + mk3(a[0], a[1], a[2]);
@@ -1603,6 +1687,8 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         if (t.width == 0 || t.height == 0 || t.offset + (uint64_t)t.width * t.height > desc->n_texels)
             return fail(SRT_ERR_INVALID, "texture %u does not fit the texel array", i);
     }
+    if (desc->environment > desc->n_textures)
+        return fail(SRT_ERR_INVALID, "environment image %u outside %u textures", desc->environment, desc->n_textures);
     for (uint32_t i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].type > 2)
             return fail(SRT_ERR_INVALID, "light %u: unknown type %u", i, desc->lights[i].type);
@@ -1638,6 +1724,7 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     for (int k = 0; k < 3; ++k)
         v.root_lo[k] = desc->root_box[k], v.root_hi[k] = desc->root_box[3 + k];
     v.n_texels = desc->n_texels;
+    v.env_tex = desc->environment ? (int32_t)desc->environment - 1 : -1;
     auto coord_ok = [](float c) {
         uint32_t b;
         memcpy(&b, &c, 4);
@@ -1763,8 +1850,17 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 32 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
+    if (rp.lens_mode && rp.lens.samples == 0) {
+        /* motion blur / depth of field with zero samples: the reference's loops do not run and the pixel stays black */
+        const uint32_t npx = (uint32_t)rp.tw * (uint32_t)rp.th;
+        int gr = (int)((npx + SRT_BLOCK - 1) / SRT_BLOCK);
+        if (gr > d->n_cu * 8) gr = d->n_cu * 8;
+        hipLaunchKernelGGL(k_resolve, dim3(gr), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc);
+        HIPCHK(hipGetLastError());
+        return SRT_OK;
+    }
     mark(d, st, 0, timing);
-    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0);
+    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0, acc);
     const bool branching = (rp.features & SRT_F_TRANSPARENCY) != 0;
     const int last_depth = (rp.features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY)) ? rp.max_depth : 0;
     for (int depth = 0; depth <= last_depth; ++depth) {
@@ -1807,7 +1903,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         }
         mark(d, st, 1, timing);
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
-            path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1);
+            path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc);
     }
     mark(d, st, 3, timing);
     const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
@@ -1902,6 +1998,17 @@ static int rect_setup(srt_device* d, srt_scene* sc, const srt_render_params* p, 
     }
     if (p->max_depth < 0 || p->max_depth > 30)
         return fail(SRT_ERR_INVALID, "max_depth %d outside [0,30]", p->max_depth);
+    /* the else-if chain of reference src/render.cpp:196-227: multisampling, else motion blur, else depth of field */
+    int lens_mode = 0;
+    if (!(p->features & SRT_F_MULTISAMPLE))
+        lens_mode = (p->features & SRT_F_MOTION_BLUR) ? 1 : ((p->features & SRT_F_DEPTH_OF_FIELD) ? 2 : 0);
+    if (lens_mode) {
+        if (p->lens.samples < 0 || p->lens.samples > 4096)
+            return fail(SRT_ERR_INVALID, "lens.samples %d outside [0,4096]", p->lens.samples);
+        nsx = p->lens.samples > 0 ? p->lens.samples : 1, nsy = 1; /* with zero samples nothing is traced, one unused slot per pixel */
+    }
+    if ((p->features & SRT_F_ENVIRONMENT) && sc->view.env_tex < 0)
+        return fail(SRT_ERR_INVALID, "SRT_F_ENVIRONMENT: the scene was uploaded without an environment image");
     /* sample slots: the rectangle padded to whole 8 x 8-pixel blocks (sample_decode) */
     const uint64_t n64 = (uint64_t)((x1 - x0 + 7) / 8) * (uint64_t)((y1 - y0 + 7) / 8) * 64ull * (uint64_t)(nsx * nsy);
     if (n64 >= (1ull << 31))
@@ -1917,6 +2024,8 @@ static int rect_setup(srt_device* d, srt_scene* sc, const srt_render_params* p, 
     rp.x0 = x0, rp.y0 = y0, rp.tw = x1 - x0, rp.th = y1 - y0;
     rp.n_samples = (uint32_t)n64;
     rp.out_w = out->out_width, rp.out_h = out->out_height, rp.out_x0 = out->x0, rp.out_y0 = out->y0;
+    rp.lens = p->lens;
+    rp.lens_mode = lens_mode;
     *rpo = rp;
     return SRT_OK;
 }

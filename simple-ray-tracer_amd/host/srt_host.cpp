@@ -67,6 +67,9 @@ uint32_t featureMask(const Features& f, bool referenceTraversal)
     if (f.enableAccelStructure) m |= SRT_F_ACCEL;
     if (f.extra.enableMultipleRaysPerPixel) m |= SRT_F_MULTISAMPLE;
     if (f.extra.enableTransparency) m |= SRT_F_TRANSPARENCY;
+    if (f.extra.enableMotionBlur) m |= SRT_F_MOTION_BLUR;
+    if (f.extra.enableDepthOfField) m |= SRT_F_DEPTH_OF_FIELD;
+    if (f.extra.enableEnvironmentMapping) m |= SRT_F_ENVIRONMENT;
     if (!referenceTraversal) m |= SRT_F_MISS_CULL;
     return m;
 }
@@ -282,6 +285,7 @@ srt_scene_desc FlatScene::desc() const
     d.n_texels = texels.size() / 3;
     d.lights = lights.data();
     d.n_lights = (uint32_t)lights.size();
+    d.environment = environment;
     return d;
 }
 
@@ -432,6 +436,19 @@ FlatScene BoundingVolumeHierarchy::flatten(int bfsLevels) const
             }
         }
         f.materials.push_back(m);
+    }
+    if (const Image* im = scene.environment.get()) {
+        auto it = std::find(seen.begin(), seen.end(), im);
+        if (it == seen.end()) {
+            f.textures.push_back({ (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) });
+            f.texels.reserve(f.texels.size() + 3 * im->pixels.size());
+            for (const vec3& p : im->pixels)
+                f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
+            seen.push_back(im);
+            f.environment = (uint32_t)seen.size();
+        } else {
+            f.environment = (uint32_t)(it - seen.begin()) + 1;
+        }
     }
     for (const Light& l : scene.lights) {
         srt_light o {};
@@ -666,20 +683,9 @@ Ray Trackball::generateRay(const vec2& pixel) const
 
 /* ------------------------------------------------------------------------------------------ frame */
 
-static void rejectUnsupported(const Features& f)
-{
-    const char* what = nullptr;
-    if (f.extra.enableEnvironmentMapping) what = "environment mapping";
-    else if (f.extra.enableMotionBlur) what = "motion blur";
-    else if (f.extra.enableDepthOfField) what = "depth of field";
-    if (what)
-        throw std::runtime_error(std::string("feature not implemented by the MI355X back end: ") + what);
-}
-
-void renderRayTracing(const Scene&, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const int& numRays,
+void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const int& numRays,
                       const RenderOptions& opt)
 {
-    rejectUnsupported(features);
     const ivec2 res = screen.resolution();
     srt_render_params p {};
     p.camera = camera.deviceCamera(res.x, res.y);
@@ -692,6 +698,12 @@ void renderRayTracing(const Scene&, const Trackball& camera, const BvhInterface&
     p.rect[0] = whole ? 0 : opt.rect[0], p.rect[1] = whole ? 0 : opt.rect[1];
     p.rect[2] = whole ? res.x : opt.rect[2], p.rect[3] = whole ? res.y : opt.rect[3];
     p.flags = (opt.stats ? SRT_RENDER_STATS : 0u) | (opt.timing ? SRT_RENDER_TIMING : 0u);
+    /* the Scene's motion-blur / depth-of-field variables, reference src/scene.h:32-40 (motion blur wins, src/render.cpp:218-223) */
+    p.lens.samples = features.extra.enableMotionBlur ? scene.MB_samples : scene.DOF_samples;
+    p.lens.time0 = scene.time0, p.lens.time1 = scene.time1;
+    p.lens.direction[0] = scene.directionVector.x, p.lens.direction[1] = scene.directionVector.y, p.lens.direction[2] = scene.directionVector.z;
+    p.lens.focal_length = (float)scene.focalLength;
+    p.lens.aperture = scene.aperture;
     srt_output out {};
     static_assert(sizeof(vec3) == 12, "Screen pixels are packed floats");
     out.rgb = &screen.pixels()[0].x;
@@ -715,7 +727,6 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
 
 vec3 getFinalColor(const Scene&, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth)
 {
-    rejectUnsupported(features);
     const float r[7] = { ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, ray.t };
     float rgb[3] = { 0, 0, 0 };
     /* a ray that starts at recursion depth d may bounce 5 - d more times */

@@ -172,7 +172,14 @@ struct Scene {
     int focalLength = 0;
     float aperture = 0;
     int DOF_samples = 0;
+    /* The image extra.enableEnvironmentMapping looks misses up in.  The reference keeps it in a global loaded from
+     * DATA_DIR/cube_map.jpg when the program starts (src/render.cpp:38); here it belongs to the scene and must be
+     * set (loadEnvironment, or any Image) before the BvhInterface is constructed. */
+    std::shared_ptr<Image> environment;
 };
+
+/* Image of <dataDir>/cube_map.jpg, the file the reference's environment map comes from. */
+std::shared_ptr<Image> loadEnvironment(const std::filesystem::path& dataDir);
 
 Scene loadScenePrebuilt(SceneType type, const std::filesystem::path& dataDir);
 Scene loadSceneFromFile(const std::filesystem::path& path, const std::vector<Light>& lights);
@@ -229,6 +236,7 @@ struct FlatScene {
     float rootBox[6] = { 0, 0, 0, 0, 0, 0 };
     uint32_t rootRef = SRT_LEAF_FLAG;
     uint32_t numLevels = 0;
+    uint32_t environment = 0; /* 1 + index of the environment image in textures, 0 for none */
     srt_scene_desc desc() const;
 };
 

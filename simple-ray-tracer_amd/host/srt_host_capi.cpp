@@ -43,6 +43,9 @@ static Features featuresFromMask(uint32_t m)
     f.extra.enableBvhSahBinning = m & SRTH_F_SAH;
     f.extra.enableBloomEffect = m & SRTH_F_BLOOM;
     f.extra.enableTransparency = m & SRT_F_TRANSPARENCY;
+    f.extra.enableMotionBlur = m & SRT_F_MOTION_BLUR;
+    f.extra.enableDepthOfField = m & SRT_F_DEPTH_OF_FIELD;
+    f.extra.enableEnvironmentMapping = m & SRT_F_ENVIRONMENT;
     return f;
 }
 
@@ -74,6 +77,33 @@ int srth_scene_add_texture(srth_scene* s, int w, int h, const float* rgb)
     std::memcpy(im->pixels.data(), rgb, (size_t)w * h * 12);
     s->textures.push_back(im);
     return (int)s->textures.size() - 1;
+}
+
+/* Scene::environment from float RGB rows (top row first). */
+int srth_scene_set_environment(srth_scene* s, int w, int h, const float* rgb)
+{
+    auto im = std::make_shared<Image>();
+    im->width = w, im->height = h;
+    im->pixels.resize((size_t)w * h);
+    std::memcpy(im->pixels.data(), rgb, (size_t)w * h * 12);
+    s->scene.environment = im;
+    return 0;
+}
+/* Scene::environment = loadEnvironment(dataDir), i.e. <dataDir>/cube_map.jpg */
+int srth_scene_load_environment(srth_scene* s, const char* dataDir) { SRTH_TRY(s->scene.environment = loadEnvironment(dataDir)) }
+/* The Scene's motion-blur and depth-of-field variables (reference src/scene.h:32-40). */
+int srth_scene_set_lens(srth_scene* s, int mbSamples, float time0, float time1, const float* direction3, int focalLength, float aperture, int dofSamples)
+{
+    s->scene.MB_samples = mbSamples, s->scene.time0 = time0, s->scene.time1 = time1;
+    s->scene.directionVector = { direction3[0], direction3[1], direction3[2] };
+    s->scene.focalLength = focalLength, s->scene.aperture = aperture, s->scene.DOF_samples = dofSamples;
+    return 0;
+}
+/* Image(path) as the loader decodes it: size query with rgb == NULL, then the float RGB rows. */
+int srth_image_load(const char* path, int* w, int* h, float* rgb)
+{
+    SRTH_TRY(Image im { std::filesystem::path(path) }; *w = im.width; *h = im.height;
+             if (rgb) std::memcpy(rgb, im.pixels.data(), im.pixels.size() * 12))
 }
 
 int srth_scene_add_mesh(srth_scene* s, const float* verts8, int nv, const uint32_t* tris3, int nt, const float* material8, int tex)

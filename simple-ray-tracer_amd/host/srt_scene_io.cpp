@@ -767,6 +767,8 @@ Image::Image(const std::filesystem::path& filePath)
         pixels.emplace_back(rgb[i] / 255.0f, rgb[i + 1] / 255.0f, rgb[i + 2] / 255.0f);
 }
 
+std::shared_ptr<Image> loadEnvironment(const std::filesystem::path& dataDir) { return std::make_shared<Image>(dataDir / "cube_map.jpg"); }
+
 std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNormalize)
 {
     if (!std::filesystem::exists(file)) {

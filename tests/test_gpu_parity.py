@@ -560,6 +560,84 @@ def test_transparency_final_color_batch(orc, scenes, gpu):
     assert np.abs(got - want).max() <= RGB_TOL and want.max() > 0.05
 
 
+def _environment_image(w=128, h=96):
+    """A cross-shaped cube map stand-in: smooth gradients plus a checker, quantised like a decoded image (u8 / 255)."""
+    y, x = np.mgrid[0:h, 0:w]
+    r = (x * 255 // (w - 1)).astype(np.uint8)
+    g = (y * 255 // (h - 1)).astype(np.uint8)
+    b = (((x // 8 + y // 8) % 2) * 200 + 40).astype(np.uint8)
+    return np.ascontiguousarray(np.stack([r, g, b], -1).astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("policy", ["reference", "cull"])
+def test_environment_map(orc, scenes, gpu, policy):
+    """extra.enableEnvironmentMapping (reference src/render.cpp:40-81,141-147): camera rays, reflected rays and rays
+    continued through transparent surfaces that hit nothing pick up the environment image."""
+    env = _environment_image()
+    cull = srt.F_MISS_CULL if policy == "cull" else 0
+    for name, extra, res in (("monkey", srt.F_RECURSIVE | srt.F_NORMAL_INTERP, (96, 72)), ("cube", srt.F_TRANSPARENCY | srt.F_RECURSIVE, (64, 48)),
+                             ("cornell", srt.F_RECURSIVE, (64, 64))):
+        d = dict(scenes(name))
+        d["lights"] = np.ascontiguousarray(np.stack([orc.point_light((-1, 1.5, -1))]))
+        scene = srt.Scene.from_arrays(d)
+        scene.set_environment(env)
+        ob, gb = orc.Bvh(d, orc.F_ACCEL), srt.Bvh(scene, srt.F_ACCEL)
+        feat = SH | srt.F_HARD_SHADOW | extra | srt.F_ENVIRONMENT | cull
+        want = ob.render(orc.make_camera(*res), feat, environment=env)
+        got = gb.render(srt.make_camera(*res), feat)
+        _compare_frames(got, want, f"environment map, {name}/{policy}")
+        plain = gb.render(srt.make_camera(*res), feat & ~srt.F_ENVIRONMENT)
+        miss = got["tri"] < 0
+        assert miss.any() and (got["rgb"][miss].max(axis=1) > 0).mean() > 0.9 and not plain["rgb"][miss].any()
+        if name != "cornell":  # the box is closed towards everything but the camera: its mirror sees walls only
+            assert np.abs(got["rgb"][~miss] - plain["rgb"][~miss]).max() > 0.02  # reflections / transmission see it too
+        rays = _rays_for(orc, d, 800, 17)
+        want_rgb, _ = ob.final_color(rays, feat, environment=env)
+        assert np.abs(gb.final_color(rays, feat) - want_rgb).max() <= RGB_TOL
+    # a scene uploaded without an environment image refuses the flag
+    _, bare = orc.Bvh(scenes("cube"), orc.F_ACCEL), srt.Bvh(srt.Scene.from_arrays(scenes("cube")), srt.F_ACCEL)
+    with pytest.raises(srt.SrtError, match="environment"):
+        bare.render(srt.make_camera(16, 16), SH | srt.F_ENVIRONMENT)
+
+
+@pytest.mark.parametrize("mode", ["motion_blur", "depth_of_field"])
+def test_lens_effects(orc, scenes, pair, mode):
+    """extra.enableMotionBlur / enableDepthOfField (reference src/render.cpp:152-178,218-223) with the jitter drawn
+    from the shared counter-based generator (the reference uses rand(): parity against the reference itself is
+    unpinned for these two, as for soft shadows)."""
+    ob, gb = pair("monkey")
+    flag = srt.F_MOTION_BLUR if mode == "motion_blur" else srt.F_DEPTH_OF_FIELD
+    lens = dict(samples=6, time0=0.1, time1=0.9, direction=(1.0, 0.5, 0.0), focal_length=3, aperture=0.05)
+    feat = FEATURE_SETS["recursive"] | srt.F_MISS_CULL | flag
+    want = ob.render(orc.make_camera(80, 60), feat, seed=5, lens=lens)
+    got = gb.render(srt.make_camera(80, 60), feat, seed=5, lens=lens)
+    _compare_frames(got, want, mode)
+    wc, gc = want["counters"], got["counters"]
+    assert (gc["path_rays"], gc["shadow_rays"], gc["shaded_hits"]) == (wc["path_rays"], wc["shadow_rays"], wc["shaded_hits"])
+    assert gc["path_rays"] >= 80 * 60 * 6
+    sharp = gb.render(srt.make_camera(80, 60), feat & ~flag)
+    assert np.abs(sharp["rgb"] - got["rgb"]).max() > 0.05  # the effect is visible
+    assert np.abs(gb.render(srt.make_camera(80, 60), feat, seed=6, lens=lens)["rgb"] - got["rgb"]).max() > 0
+    # a rectangle of the frame equals the frame (sampler keys are frame global)
+    part = gb.render(srt.make_camera(80, 60), feat, seed=5, lens=lens, rect=(16, 8, 61, 43))["rgb"]
+    assert np.array_equal(part[60 - 43:60 - 8, 16:61].view(np.uint32), got["rgb"][60 - 43:60 - 8, 16:61].view(np.uint32))
+    # zero samples: the reference's loop does not run, the frame is black
+    none = gb.render(srt.make_camera(80, 60), feat, lens=dict(lens, samples=0))
+    assert not none["rgb"].any() and not ob.render(orc.make_camera(80, 60), feat, lens=dict(lens, samples=0))["rgb"].any()
+    # precedence (src/render.cpp:196-227): multisampling over motion blur over depth of field
+    both = feat | srt.F_MOTION_BLUR | srt.F_DEPTH_OF_FIELD
+    mb = gb.render(srt.make_camera(80, 60), (feat & ~flag) | srt.F_MOTION_BLUR, seed=5, lens=lens)
+    assert np.array_equal(gb.render(srt.make_camera(80, 60), both, seed=5, lens=lens)["rgb"], mb["rgb"])
+    ms = gb.render(srt.make_camera(80, 60), (feat & ~flag) | srt.F_MULTISAMPLE, nsx=2, nsy=2)
+    assert np.array_equal(gb.render(srt.make_camera(80, 60), both | srt.F_MULTISAMPLE, nsx=2, nsy=2, seed=5, lens=lens)["rgb"], ms["rgb"])
+    # the C++ mirror takes the variables from the Scene, as the reference does
+    gb.scene.set_lens(mb_samples=6, time0=0.1, time1=0.9, direction=(1.0, 0.5, 0.0), focal_length=3, aperture=0.05, dof_samples=6)
+    mirror = srt.mirror_render(gb, feat, 80, 60)
+    want0 = ob.render(orc.make_camera(80, 60), feat, seed=0, lens=lens)["rgb"]
+    assert np.abs(mirror - want0).max() <= RGB_TOL
+    gb.scene.set_lens()
+
+
 def test_bloom_through_the_mirror(orc, pair):
     """renderRayTracing with extra.enableBloomEffect and the parameters the reference's callers pass (threshold 0.5,
     boxSize 1 -> a 3-box): the frame, then Screen::applyBloomFilter on it."""
