@@ -9,8 +9,11 @@ checkout exists; the fixtures it writes are plain data (inputs and the reference
   tests/golden/camera.npz          glm camera arithmetic as used by framework/src/trackball.cpp
   tests/golden/obj_cases/*.npz     the reference loader's output for the OBJ files authored in that directory
   tests/golden/screen_bmp.npz      float pixels and the bytes of the .bmp file the reference's writer makes of them
+  tests/golden/image_cases/        small JPEG / interlaced PNG files written here with Pillow, and expected.npz: what the
+                                   reference's Image loader (stb_image) decodes each of them to; cube_map.npz: SHA-256 and
+                                   a 1/16 sub-grid of the reference's decode of its own data/cube_map.jpg
 
-usage: make_golden.py [scenes|leaf|camera|obj|bmp ...]   (default: all)
+usage: make_golden.py [scenes|leaf|camera|obj|bmp|images ...]   (default: all)
 """
 import ctypes as C
 import os
@@ -245,10 +248,143 @@ def gen_bitmap():
     print("bmp fixture:", len(data), "bytes")
 
 
+def gen_images():
+    """Test images made here (a photo-like synthetic picture saved in the formats the loader has to read) and the
+    reference loader's decode of each."""
+    import hashlib
+    from PIL import Image as PI
+    out_dir = os.path.join(GOLD, "image_cases")
+    os.makedirs(out_dir, exist_ok=True)
+    rng = np.random.default_rng(11)
+
+    def picture(w, h):
+        y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+        r = 127 + 120 * np.sin(x / 5.0) * np.cos(y / 7.0)
+        g = 255 * (x + y) / max(1, w + h - 2)
+        b = 255 * (((x // 6 + y // 4) % 2) * 0.7 + 0.15) + rng.normal(0, 6, (h, w))
+        return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+
+    cases = []
+    def jpeg(name, w, h, mode="RGB", **kw):
+        img = PI.fromarray(picture(w, h)).convert(mode)
+        img.save(os.path.join(out_dir, name + ".jpg"), "JPEG", **kw)
+        cases.append(name + ".jpg")
+
+    def png(name, w, h, mode="RGB", bits=None, **kw):
+        img = PI.fromarray(picture(w, h)).convert(mode)
+        if mode == "P" and bits:
+            img = PI.fromarray(picture(w, h)).quantize(1 << bits)
+        # Pillow cannot write interlaced files: interlace them here (Adam7), from Pillow's non-interlaced output
+        path = os.path.join(out_dir, name + ".png")
+        img.save(path, "PNG", bits=bits, **kw) if bits and mode == "P" else img.save(path, "PNG", **kw)
+        _interlace_png(path)
+        cases.append(name + ".png")
+
+    jpeg("base444", 40, 24, quality=90, subsampling=0)
+    jpeg("base420_odd", 37, 29, quality=85, subsampling=2)
+    jpeg("base422", 35, 18, quality=80, subsampling=1)
+    jpeg("base_gray", 33, 17, mode="L", quality=88)
+    jpeg("base420_restart", 50, 41, quality=75, subsampling=2, restart_marker_blocks=3)
+    jpeg("base_optimized", 48, 32, quality=60, subsampling=2, optimize=True)
+    jpeg("prog444", 40, 27, quality=90, subsampling=0, progressive=True)
+    jpeg("prog420_odd", 45, 35, quality=80, subsampling=2, progressive=True)
+    jpeg("prog_gray", 31, 22, mode="L", quality=85, progressive=True)
+    jpeg("prog422_restart", 52, 30, quality=70, subsampling=1, progressive=True, restart_marker_rows=1)
+    jpeg("tiny_1x1", 1, 1, quality=90)
+    jpeg("low_quality", 64, 48, quality=8, subsampling=2)
+    png("ilace_rgb", 13, 11)
+    png("ilace_rgba", 9, 10, mode="RGBA")
+    png("ilace_gray", 17, 5, mode="L")
+    png("ilace_pal4", 21, 19, mode="P", bits=4)
+    png("ilace_1x1", 1, 1)
+    png("ilace_2x3", 2, 3)
+    expected = {}
+    for f in cases:
+        rgb = orc.ref_image(os.path.join(out_dir, f))
+        assert rgb is not None, f
+        u8 = np.rint(rgb * 255.0).astype(np.uint8)
+        assert np.array_equal(u8.astype(np.float32) / np.float32(255.0), rgb)
+        expected[f] = u8
+        print(f"{f}: {u8.shape[1]}x{u8.shape[0]}")
+    np.savez_compressed(os.path.join(out_dir, "expected.npz"), **expected)
+    big = orc.ref_image(os.path.join(DATA, "cube_map.jpg"))
+    u8 = np.rint(big * 255.0).astype(np.uint8)
+    assert np.array_equal(u8.astype(np.float32) / np.float32(255.0), big)
+    np.savez_compressed(os.path.join(out_dir, "cube_map.npz"), sha256=np.frombuffer(hashlib.sha256(u8.tobytes()).digest(), np.uint8),
+                        shape=np.array(u8.shape, np.int64), grid16=u8[::16, ::16].copy())
+    print("cube_map.jpg:", u8.shape, hashlib.sha256(u8.tobytes()).hexdigest())
+
+
+def _interlace_png(path):
+    """Rewrite a non-interlaced 8/16-bit or palette PNG as an Adam7-interlaced one (filter type 0 on every line)."""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    pos, chunks = 8, []
+    while pos < len(data):
+        n = struct.unpack(">I", data[pos:pos + 4])[0]
+        chunks.append((data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]))
+        pos += 12 + n
+    ihdr = dict(chunks)[b"IHDR"]
+    w, h, depth, ctype = struct.unpack(">IIBB", ihdr[:10])
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    bits = ch * depth
+    stride = (w * bits + 7) // 8
+    raw = zlib.decompress(b"".join(d for t, d in chunks if t == b"IDAT"))
+    bpp = max(1, bits // 8)
+    rows, prev = [], bytearray(stride)
+    for y in range(h):
+        f = raw[y * (stride + 1)]
+        line = bytearray(raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)])
+        for i in range(stride):
+            a = line[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 1:
+                line[i] = (line[i] + a) & 255
+            elif f == 2:
+                line[i] = (line[i] + b) & 255
+            elif f == 3:
+                line[i] = (line[i] + ((a + b) >> 1)) & 255
+            elif f == 4:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                line[i] = (line[i] + (a if pa <= pb and pa <= pc else (b if pb <= pc else c))) & 255
+        rows.append(line)
+        prev = line
+
+    def pixel_bits(y, x):
+        v = int.from_bytes(rows[y], "big")
+        return (v >> (stride * 8 - (x + 1) * bits)) & ((1 << bits) - 1)
+
+    out = bytearray()
+    for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        pw, ph = (w - x0 + dx - 1) // dx if w > x0 else 0, (h - y0 + dy - 1) // dy if h > y0 else 0
+        if pw <= 0 or ph <= 0:
+            continue
+        ps = (pw * bits + 7) // 8
+        for j in range(ph):
+            acc = 0
+            for i in range(pw):
+                acc = (acc << bits) | pixel_bits(y0 + j * dy, x0 + i * dx)
+            acc <<= ps * 8 - pw * bits
+            out += b"\0" + acc.to_bytes(ps, "big")
+    new = bytearray(data[:8])
+    done = False
+    for t, d in chunks:
+        if t == b"IHDR":
+            d = d[:12] + b"\1"
+        if t == b"IDAT":
+            if done:
+                continue
+            d, done = zlib.compress(bytes(out)), True
+        new += struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    open(path, "wb").write(bytes(new))
+
+
 if __name__ == "__main__":
     if not orc.ref_available():
         orc.build()
-    what = sys.argv[1:] or ["scenes", "leaf", "camera", "obj", "bmp"]
+    what = sys.argv[1:] or ["scenes", "leaf", "camera", "obj", "bmp", "images"]
     if "scenes" in what or "leaf" in what:
         scenes = gen_scenes()
         if "leaf" in what:
@@ -259,4 +395,6 @@ if __name__ == "__main__":
         gen_obj_cases()
     if "bmp" in what:
         gen_bitmap()
+    if "images" in what:
+        gen_images()
     print("golden fixtures written to", GOLD)

@@ -388,6 +388,7 @@ def ref():
         R.ref_glm_camera.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p]
         R.ref_glm_camera_rays.argtypes = [C.c_float, C.c_float, _f32p, _f32p, C.c_int, C.c_int, _f32p, _f32p, C.c_long]
         R.ref_write_bmp.argtypes = [C.c_char_p, C.c_int, C.c_int, _f32p]
+        R.ref_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), _f32p]
         _ref = R
     return _ref
 
@@ -445,3 +446,14 @@ def ref_scene_to_dict(h):
         R.ref_scene_light_get(h, i, _ptr(L[i], _f32p))
     d["lights"] = L
     return d
+
+
+def ref_image(path):
+    """The reference's Image(path): float RGB (H, W, 3), or None where the reference throws."""
+    R = ref()
+    w, h = C.c_int(), C.c_int()
+    if R.ref_image_load(os.fsencode(path), C.byref(w), C.byref(h), None) != 0:
+        return None
+    rgb = np.zeros((h.value, w.value, 3), np.float32)
+    R.ref_image_load(os.fsencode(path), C.byref(w), C.byref(h), _ptr(rgb, _f32p))
+    return rgb

@@ -249,6 +249,21 @@ void ref_glm_camera_rays(float fovy_deg, float dist, const float* look_at3, cons
     }
 }
 
+/* Image::Image (framework/src/image.cpp:13-35: stb_image, three channels, u8 / 255.0f).  Size query with rgb == NULL;
+ * returns 0 on success, -1 when the reference throws. */
+int ref_image_load(const char* path, int* w, int* h, float* rgb)
+{
+    try {
+        Image im { std::filesystem::path(path) };
+        *w = im.width, *h = im.height;
+        if (rgb)
+            std::memcpy(rgb, im.pixels.data(), im.pixels.size() * sizeof(glm::vec3));
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
 /* What Screen::writeBitmapToFile (src/screen.cpp:93-104) hands to stb: clamp, scale by 255, convert to bytes. */
 int ref_write_bmp(const char* path, int w, int h, const float* rgb)
 {

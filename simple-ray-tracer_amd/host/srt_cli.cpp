@@ -56,6 +56,12 @@ int main(int argc, char** argv)
             scene = loadScenePrebuilt(type, config.dataPath);
             sceneName = serialize(type);
         }
+        scene.MB_samples = config.backend.mbSamples, scene.time0 = config.backend.time0, scene.time1 = config.backend.time1;
+        scene.directionVector = config.backend.direction;
+        scene.DOF_samples = config.backend.dofSamples, scene.focalLength = config.backend.focalLength, scene.aperture = config.backend.aperture;
+        /* the reference reads the environment map from its compiled-in data directory (src/render.cpp:38) */
+        if (config.features.extra.enableEnvironmentMapping)
+            scene.environment = loadEnvironment(config.dataPath.empty() ? defaultDataDir() : config.dataPath);
         Features features = config.features;
         features.enableSoftShadow = config.backend.enableSoftShadow;
         features.extra.enableTransparency = config.backend.enableTransparency;

@@ -100,7 +100,10 @@ std::ostream& operator<<(std::ostream& os, const Config& config)
        << "    - enable_transparency: " << b.enableTransparency << std::endl
        << "    - traversal: " << (b.referenceTraversal ? "reference" : "miss-cull") << std::endl
        << "    - max_depth: " << b.maxDepth << std::endl
-       << "    - seed: " << b.seed << std::endl;
+       << "    - seed: " << b.seed << std::endl
+       << "    - motion blur: samples " << b.mbSamples << ", time0 " << b.time0 << ", time1 " << b.time1 << ", direction [" << b.direction.x << ", "
+       << b.direction.y << ", " << b.direction.z << "]" << std::endl
+       << "    - depth of field: samples " << b.dofSamples << ", focal_length " << b.focalLength << ", aperture " << b.aperture << std::endl;
     return os;
 }
 
@@ -274,6 +277,13 @@ static Config fromTable(const toml::Value& table)
         b.seed = (uint32_t)integerKey(backend["seed"], "seed", 0, 0, 0xFFFFFFFFll);
         optionalBool(backend["enable_soft_shadow"], b.enableSoftShadow);
         optionalBool(backend["enable_transparency"], b.enableTransparency);
+        b.mbSamples = (int)integerKey(backend["mb_samples"], "mb_samples", 0, 0, 4096);
+        b.dofSamples = (int)integerKey(backend["dof_samples"], "dof_samples", 0, 0, 4096);
+        b.focalLength = (int)integerKey(backend["focal_length"], "focal_length", 0, 0, 1000000);
+        b.time0 = number(backend["time0"], 0.0f), b.time1 = number(backend["time1"], 0.0f);
+        b.aperture = number(backend["aperture"], 0.0f);
+        if (backend["direction"].kind == toml::Value::ArrayKind)
+            b.direction = arrayToVec3(backend["direction"]);
         if (backend["traversal"].kind == toml::Value::String) {
             if (backend["traversal"].s == "reference")
                 b.referenceTraversal = true;

@@ -30,6 +30,11 @@ struct BackendConfig {
     bool referenceTraversal = false; /* "traversal" = "reference" | "miss-cull" */
     int maxDepth = 5;
     uint32_t seed = 0;
+    /* The Scene's motion-blur / depth-of-field variables, which the reference only sets from sliders of its viewer
+     * (src/main.cpp:254-262); its command-line path leaves DOF_samples at 0 and MB_samples uninitialised. */
+    int mbSamples = 0, dofSamples = 0, focalLength = 0;
+    float time0 = 0.0f, time1 = 0.0f, aperture = 0.0f;
+    vec3 direction = { 0.0f, 0.0f, 0.0f };
 };
 
 struct Config {

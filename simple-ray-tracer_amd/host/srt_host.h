@@ -54,7 +54,7 @@ struct ivec2 {
 
 struct Image {
     Image() = default;
-    explicit Image(const std::filesystem::path& filePath); /* PNG decode; throws std::exception like the reference */
+    explicit Image(const std::filesystem::path& filePath); /* PNG or JPEG, decoded to the pixels stb_image gives; throws std::exception like the reference */
     int width = 0, height = 0;
     std::vector<vec3> pixels; /* u8 / 255.0f, row-major, top row first */
 };

@@ -680,65 +680,88 @@ bool decodePng(const std::vector<uint8_t>& file, int& w, int& h, std::vector<uin
         }
         pos += 12 + len;
     }
-    if (!gotHeader || w <= 0 || h <= 0 || interlace != 0)
+    if (!gotHeader || w <= 0 || h <= 0 || interlace > 1)
         return false;
     int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!channels || (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16))
         return false;
     const size_t bitsPerPixel = (size_t)channels * depth;
-    const size_t stride = ((size_t)w * bitsPerPixel + 7) / 8;
     const size_t bpp = std::max<size_t>(1, bitsPerPixel / 8);
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    /* The image is stored as one pass, or (Adam7 interlacing) as seven reduced images: pass p holds the pixels
+     * (x0 + i * dx, y0 + j * dy), each pass filtered like an image of its own. */
+    struct Pass {
+        int x0, y0, dx, dy;
+    };
+    static const Pass adam7[7] = { { 0, 0, 8, 8 }, { 4, 0, 8, 8 }, { 0, 4, 4, 8 }, { 2, 0, 4, 4 }, { 0, 2, 2, 4 }, { 1, 0, 2, 2 }, { 0, 1, 1, 2 } };
+    static const Pass whole = { 0, 0, 1, 1 };
+    const int nPasses = interlace ? 7 : 1;
+    size_t rawSize = 0;
+    for (int p = 0; p < nPasses; ++p) {
+        const Pass& ps = interlace ? adam7[p] : whole;
+        const size_t pw = (size_t)(w - ps.x0 + ps.dx - 1) / ps.dx, ph = (size_t)(h - ps.y0 + ps.dy - 1) / ps.dy;
+        if (w > ps.x0 && h > ps.y0 && pw && ph)
+            rawSize += ((pw * bitsPerPixel + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw(rawSize);
     uLongf rawLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
         return false;
-    std::vector<uint8_t> img(stride * (size_t)h);
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* in = &raw[(stride + 1) * (size_t)y];
-        const int filter = in[0];
-        ++in;
-        uint8_t* cur = &img[stride * (size_t)y];
-        const uint8_t* up = y ? &img[stride * (size_t)(y - 1)] : nullptr;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int x = in[i];
-            switch (filter) {
-            case 0: break;
-            case 1: x += a; break;
-            case 2: x += b; break;
-            case 3: x += (a + b) >> 1; break;
-            case 4: x += paeth(a, b, c); break;
-            default: return false;
-            }
-            cur[i] = (uint8_t)x;
-        }
-    }
-    rgb.resize((size_t)w * h * 3);
+    rgb.assign((size_t)w * h * 3, 0);
     static const int depthScale[9] = { 0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01 };
-    for (int y = 0; y < h; ++y) {
-        const uint8_t* row = &img[stride * (size_t)y];
-        for (int x = 0; x < w; ++x) {
-            auto sample = [&](int ch) -> int {
-                if (depth == 16)
-                    return row[((size_t)x * channels + ch) * 2];
-                if (depth == 8)
-                    return row[(size_t)x * channels + ch];
-                size_t bit = ((size_t)x * channels + ch) * depth;
-                return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-            };
-            uint8_t* o = &rgb[((size_t)y * w + x) * 3];
-            if (ctype == 3) {
-                size_t idx = (size_t)sample(0);
-                if (idx * 3 + 2 >= plte.size())
-                    return false;
-                o[0] = plte[idx * 3], o[1] = plte[idx * 3 + 1], o[2] = plte[idx * 3 + 2];
-            } else if (ctype == 0 || ctype == 4) {
-                int g = sample(0);
-                if (depth < 8)
-                    g *= depthScale[depth];
-                o[0] = o[1] = o[2] = (uint8_t)g;
-            } else {
-                o[0] = (uint8_t)sample(0), o[1] = (uint8_t)sample(1), o[2] = (uint8_t)sample(2);
+    size_t rawPos = 0;
+    for (int p = 0; p < nPasses; ++p) {
+        const Pass& ps = interlace ? adam7[p] : whole;
+        if (w <= ps.x0 || h <= ps.y0)
+            continue;
+        const int pw = (w - ps.x0 + ps.dx - 1) / ps.dx, ph = (h - ps.y0 + ps.dy - 1) / ps.dy;
+        const size_t stride = ((size_t)pw * bitsPerPixel + 7) / 8;
+        std::vector<uint8_t> img(stride * (size_t)ph);
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t* in = &raw[rawPos + (stride + 1) * (size_t)y];
+            const int filter = in[0];
+            ++in;
+            uint8_t* cur = &img[stride * (size_t)y];
+            const uint8_t* up = y ? &img[stride * (size_t)(y - 1)] : nullptr;
+            for (size_t i = 0; i < stride; ++i) {
+                int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+                int x = in[i];
+                switch (filter) {
+                case 0: break;
+                case 1: x += a; break;
+                case 2: x += b; break;
+                case 3: x += (a + b) >> 1; break;
+                case 4: x += paeth(a, b, c); break;
+                default: return false;
+                }
+                cur[i] = (uint8_t)x;
+            }
+        }
+        rawPos += (stride + 1) * (size_t)ph;
+        for (int y = 0; y < ph; ++y) {
+            const uint8_t* row = &img[stride * (size_t)y];
+            for (int x = 0; x < pw; ++x) {
+                auto sample = [&](int ch) -> int {
+                    if (depth == 16)
+                        return row[((size_t)x * channels + ch) * 2];
+                    if (depth == 8)
+                        return row[(size_t)x * channels + ch];
+                    size_t bit = ((size_t)x * channels + ch) * depth;
+                    return (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                };
+                uint8_t* o = &rgb[((size_t)(ps.y0 + y * ps.dy) * w + (size_t)(ps.x0 + x * ps.dx)) * 3];
+                if (ctype == 3) {
+                    size_t idx = (size_t)sample(0);
+                    if (idx * 3 + 2 >= plte.size())
+                        return false;
+                    o[0] = plte[idx * 3], o[1] = plte[idx * 3 + 1], o[2] = plte[idx * 3 + 2];
+                } else if (ctype == 0 || ctype == 4) {
+                    int g = sample(0);
+                    if (depth < 8)
+                        g *= depthScale[depth];
+                    o[0] = o[1] = o[2] = (uint8_t)g;
+                } else {
+                    o[0] = (uint8_t)sample(0), o[1] = (uint8_t)sample(1), o[2] = (uint8_t)sample(2);
+                }
             }
         }
     }
@@ -746,6 +769,9 @@ bool decodePng(const std::vector<uint8_t>& file, int& w, int& h, std::vector<uin
 }
 
 } // namespace
+
+/* srt_jpeg.cpp */
+bool decodeJpeg(const std::vector<uint8_t>& file, int& w, int& h, std::vector<uint8_t>& rgb);
 
 /* ------------------------------------------------------------------------------------------ public */
 
@@ -758,8 +784,8 @@ Image::Image(const std::filesystem::path& filePath)
     std::ifstream in(filePath, std::ios::binary);
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     std::vector<uint8_t> rgb;
-    if (!decodePng(bytes, width, height, rgb)) {
-        std::cerr << "Failed to read texture " << filePath << " (only non-interlaced PNG is decoded)" << std::endl;
+    if (!decodePng(bytes, width, height, rgb) && !decodeJpeg(bytes, width, height, rgb)) {
+        std::cerr << "Failed to read texture " << filePath << " (PNG and Huffman-coded 8-bit JPEG files are decoded)" << std::endl;
         throw LoadError();
     }
     pixels.reserve((size_t)width * height);

@@ -209,3 +209,56 @@ def test_cli_bitmaps_match_the_oracle(tmp_path, orc):
         first_pixel = int.from_bytes(open(path, "rb").read()[10:14], "little")
         assert np.array_equal(got[:first_pixel], want[:first_pixel])  # file and bitmap headers
         assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_cli_environment_map_and_depth_of_field(tmp_path, orc):
+    """[features.extra] enable_environment_mapping reads <data_path>/cube_map.jpg (the reference's fixed file name,
+    src/render.cpp:38) through the JPEG decoder; [mi355x] carries the depth-of-field variables the reference only has
+    sliders for.  Both frames against the oracle, which gets the reference decoder's pixels of the same JPEG."""
+    import shutil
+    data = tmp_path / "data"
+    data.mkdir()
+    for f in ("quads_groups.obj", "quads_groups.mtl"):
+        shutil.copy(os.path.join(GOLD, "obj_cases", f), data / f)
+    shutil.copy(os.path.join(GOLD, "image_cases", "prog420_odd.jpg"), data / "cube_map.jpg")
+    with np.load(os.path.join(GOLD, "image_cases", "expected.npz")) as z:
+        env = np.ascontiguousarray(z["prog420_odd.jpg"].astype(np.float32) / np.float32(255.0))
+    base = BASE.format(data=str(data), scene="quads_groups.obj", out=str(tmp_path / "out"))
+    d = orc.load_scene_npz(os.path.join(GOLD, "obj_cases", "quads_groups.norm0.npz"))
+    d["lights"] = np.stack([orc.point_light((-1.0, 1.5, -1.0))])
+    ob = orc.Bvh(d, orc.F_ACCEL)
+    light = '[[lights]]\ntype = "point"\nposition = [-1.0, 1.5, -1.0]\ncolor = [1.0, 1.0, 1.0]\n'
+    cam = "[[cameras]]\nfield_of_view = 50.0\ndistance_from_look_at = 3.0\nlook_at = [0.0, 0.0, 0.0]\nrotation = [20.0, 20.0, 0.0]\n"
+    feat = orc.F_ACCEL | orc.F_SHADING | orc.F_RECURSIVE | orc.F_HARD_SHADOW | orc.F_NORMAL_INTERP | orc.F_MISS_CULL
+    runs = [("env", base.replace("[features]", "[features]\nextra.enable_environment_mapping = true") + cam + light,
+             dict(features=feat | orc.F_ENVIRONMENT, environment=env)),
+            ("dof", base.replace("[features]", "[features]\nextra.enable_depth_of_field = true") + cam + light
+             + "[mi355x]\ndof_samples = 5\nfocal_length = 3\naperture = 0.04\nseed = 9\n",
+             dict(features=feat | orc.F_DEPTH_OF_FIELD, seed=9, lens=dict(samples=5, focal_length=3, aperture=0.04)))]
+    for name, text, kw in runs:
+        cfg = tmp_path / (name + ".toml")
+        cfg.write_text(text.replace(str(tmp_path / "out"), str(tmp_path / name)))
+        r = subprocess.run([srt.CLI, str(cfg)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        files = glob.glob(str(tmp_path / name / "quads_groups_*_cam_0.bmp"))
+        assert len(files) == 1
+        want_rgb = ob.render(orc.make_camera(64, 48), kw.pop("features"), **kw)["rgb"]
+        want_file = str(tmp_path / "want.bmp")
+        srt.write_bmp(want_file, want_rgb)
+        got = np.frombuffer(open(files[0], "rb").read(), np.uint8).astype(np.int16)
+        want = np.frombuffer(open(want_file, "rb").read(), np.uint8).astype(np.int16)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+        if name == "env":
+            assert (want_rgb.reshape(-1, 3).max(axis=1) > 0).mean() > 0.95  # the background is the environment, not black
+
+
+def test_config_lens_keys(tmp_path):
+    text = srt.config_describe(_cfg(tmp_path) + "[mi355x]\nmb_samples = 12\ntime0 = 0.25\ntime1 = 1\ndirection = [1, 0, 0.5]\ndof_samples = 3\n"
+                               "focal_length = 4\naperture = 0.125\n")
+    assert "- motion blur: samples 12, time0 0.25, time1 1, direction [1, 0, 0.5]" in text
+    assert "- depth of field: samples 3, focal_length 4, aperture 0.125" in text
+    with pytest.raises(srt.SrtError, match="mb_samples"):
+        srt.config_describe(_cfg(tmp_path) + "[mi355x]\nmb_samples = 1.5\n")
+    with pytest.raises(srt.SrtError, match="seed"):
+        srt.config_describe(_cfg(tmp_path) + "[mi355x]\nseed = -1\n")
