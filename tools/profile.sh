@@ -8,7 +8,7 @@ shift
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $O/trace.log 2>&1 || { echo "trace run failed"; tail -5 $O/trace.log; exit 1; }
-tail -1 $O/trace.log > $O/bench_line.json
+grep '^{"metric"' $O/trace.log | tail -1 > $O/bench_line.json   # the profiler prints its own lines after the program's
 # which kernels this profile belongs to (bench.py only takes counters from a summary whose hash matches its tree)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_hash())" > $O/source_hash.txt
 run_group() {
