@@ -245,6 +245,42 @@ int srt_device_kernel_times(srt_device* dev, float ms[SRT_KERNEL_FAMILIES], int3
 int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);
 void srt_scene_destroy(srt_scene* scene);
 
+/* The same scene built ON THE DEVICE from the triangle list: what BoundingVolumeHierarchy's constructor does with the
+ * Scene's meshes (reference src/bounding_volume_hierarchy.cpp:14-94, the median-split builder; the SAH variant is built
+ * on the host and goes through srt_scene_upload).  Triangle records and node boxes are computed by kernels; the node
+ * numbering follows from the triangle count; the left-to-right order of the triangles (the reference's nested
+ * std::sort calls, tie order included) is taken from `order` or, when that is NULL, worked out by the library on
+ * centroid keys.  The resulting arrays equal, bit for bit, what the host mirror's builder + flatten(0) upload
+ * (srt_scene_download reads them back). */
+typedef struct srt_build_desc {
+    const float* verts;        /* 8 floats per vertex (position, normal, texCoord: struct Vertex, reference
+                                  framework/include/framework/mesh.h:14-20), all meshes one after the other */
+    uint32_t n_verts;
+    const uint32_t* tris;      /* 3 indices into verts per triangle (mesh-local index + the mesh's first vertex), meshes in scene order */
+    const uint32_t* tri_mesh;  /* mesh of each triangle */
+    uint32_t n_tris;
+    const uint32_t* mesh_tri_off; /* n_meshes + 1: first triangle of each mesh */
+    uint32_t n_meshes;
+    const uint32_t* order;     /* optional: the triangle at position k of the leaf-ordered streams */
+    const srt_material* materials; /* one per mesh */
+    uint32_t n_materials;
+    const srt_texture* textures;
+    uint32_t n_textures;
+    const float* texels;
+    uint64_t n_texels;
+    const srt_light* lights;
+    uint32_t n_lights;
+    uint32_t environment;      /* as in srt_scene_desc */
+} srt_build_desc;
+int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out);
+/* BoundingVolumeHierarchy::numLevels() / numLeaves() (reference src/bounding_volume_hierarchy.h:42-46) and the sizes
+ * of an uploaded or built scene; any output pointer may be NULL. */
+int srt_scene_info(const srt_scene* scene, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* num_levels, uint32_t* num_leaves,
+                   uint32_t* root_ref, float root_box6[6]);
+/* Copies the scene's device arrays back (n_nodes nodes, n_tris of each other kind; NULL skips an array): lets a
+ * device-built scene be compared with a host-built one. */
+int srt_scene_download(const srt_scene* scene, srt_node* nodes, srt_tri* tris, srt_tri_attr* attrs, uint32_t* scene_order);
+
 /* renderRayTracing (reference src/render.h:17, src/render.cpp:180-234) for one rectangle of the frame. */
 int srt_render(srt_device* dev, srt_scene* scene, const srt_render_params* params, const srt_output* out,
                void* stream);

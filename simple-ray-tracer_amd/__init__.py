@@ -95,7 +95,7 @@ assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 96 and ATTR_DTYPE.ite
 HIP_ABI_SYMBOLS = ("srt_last_error", "srt_device_count", "srt_device_create", "srt_device_destroy",
                    "srt_device_synchronize", "srt_device_read_counters", "srt_device_read_kernel_counters",
                    "srt_device_kernel_times",
-                   "srt_scene_upload", "srt_scene_destroy", "srt_render", "srt_render_noalloc", "srt_intersect_batch",
+                   "srt_scene_upload", "srt_scene_destroy", "srt_scene_build", "srt_scene_info", "srt_scene_download", "srt_render", "srt_render_noalloc", "srt_intersect_batch",
                    "srt_final_color_batch", "srt_generate_rays", "srt_selftest_division", "srt_probe_gather")
 
 
@@ -154,6 +154,7 @@ def host():
     L.srth_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_render_noalloc.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.POINTER(Output), C.c_void_p]
     L.srth_read_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
+    L.srth_bvh_download.argtypes = [C.c_void_p, _u32p, C.c_void_p, C.c_void_p, C.c_void_p, _u32p, _f32p, _u32p]
     L.srth_probe_gather.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.srth_read_kernel_counters.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Counters), C.c_int]
     L.srth_kernel_times.argtypes = [C.c_void_p, _f32p, _i32p, C.c_int]
@@ -362,6 +363,18 @@ class Bvh:
 
     num_levels = property(lambda self: host().srth_bvh_num_levels(self.h))
     num_leaves = property(lambda self: host().srth_bvh_num_leaves(self.h))
+
+    def download(self):
+        """The scene's arrays as they sit on the device, in the layout of HostBvh.flatten()."""
+        sizes = np.zeros(4, np.uint32)
+        root_box, root_ref = np.zeros(6, np.float32), np.zeros(1, np.uint32)
+        _check(host().srth_bvh_download(self.h, _p(sizes, _u32p), None, None, None, None, _p(root_box), _p(root_ref, _u32p)))
+        nodes, tris = np.zeros(int(sizes[0]), NODE_DTYPE), np.zeros(int(sizes[1]), TRI_DTYPE)
+        attrs, order = np.zeros(int(sizes[1]), ATTR_DTYPE), np.zeros(int(sizes[1]), np.uint32)
+        _check(host().srth_bvh_download(self.h, _p(sizes, _u32p), nodes.ctypes.data, tris.ctypes.data, attrs.ctypes.data, _p(order, _u32p),
+                                        _p(root_box), _p(root_ref, _u32p)))
+        return {"nodes": nodes, "tris": tris, "attrs": attrs, "scene_order": order, "root_box": root_box, "root_ref": int(root_ref[0]),
+                "num_levels": int(sizes[2]), "num_leaves": int(sizes[3])}
 
     def intersect(self, rays7, features):
         """BvhInterface::intersect for many rays; returns (hits, updated rays, counters)."""

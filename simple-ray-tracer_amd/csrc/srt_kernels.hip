@@ -41,7 +41,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "srt_device.h"
@@ -1441,6 +1443,7 @@ struct srt_scene {
     srt_device* dev = nullptr;
     SceneDev view {};
     uint32_t num_levels = 0;
+    uint32_t num_leaves = 0;
     Grids grids[2][2]; /* [miss culling][counting kernels]; fixed at upload: they depend on the stack depth only */
     std::vector<uint32_t> light_types; /* host copy: sizes the shadow-query stage */
     std::vector<void*> allocs;
@@ -1669,6 +1672,9 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         if (depth[i] > deepest)
             deepest = depth[i];
     }
+    uint32_t n_leaves = (desc->root_ref & SRT_LEAF_FLAG) ? 1u : 0u;
+    for (uint32_t i = 0; i < desc->n_nodes; ++i)
+        n_leaves += ((desc->nodes[i].left & SRT_LEAF_FLAG) ? 1u : 0u) + ((desc->nodes[i].right & SRT_LEAF_FLAG) ? 1u : 0u);
     if (rc == SRT_OK && desc->n_nodes && deepest + 2 > desc->num_levels)
         rc = fail(SRT_ERR_INVALID, "num_levels is %u but the node table is %u levels deep", desc->num_levels, deepest + 2);
     if (rc != SRT_OK)
@@ -1697,6 +1703,7 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     srt_scene* s = new srt_scene();
     s->dev = dev;
     s->num_levels = desc->num_levels;
+    s->num_leaves = n_leaves;
     for (uint32_t i = 0; i < desc->n_lights; ++i)
         s->light_types.push_back(desc->lights[i].type);
     SceneDev& v = s->view;
@@ -2289,3 +2296,5 @@ int srt_generate_rays(srt_device* d, const srt_camera* cam, const float* ndc2, i
 }
 
 } // extern "C"
+
+#include "srt_build.h"

@@ -296,6 +296,65 @@ static void putBox(float* dst, const AxisAlignedBox& b)
     put3(dst + 3, b.upper);
 }
 
+/* materials (one per mesh), distinct textures (the environment image among them), lights */
+static void packAppearance(const Scene& scene, FlatScene& f)
+{
+    std::vector<const Image*> seen;
+    for (const Mesh& mesh : scene.meshes) {
+        srt_material m {};
+        put3(m.kd, mesh.material.kd);
+        put3(m.ks, mesh.material.ks);
+        m.shininess = mesh.material.shininess;
+        m.transparency = mesh.material.transparency;
+        m.texture = -1;
+        if (const Image* im = mesh.material.kdTexture.get()) {
+            auto it = std::find(seen.begin(), seen.end(), im);
+            if (it == seen.end()) {
+                srt_texture t { (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) };
+                f.textures.push_back(t);
+                for (const vec3& p : im->pixels)
+                    f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
+                seen.push_back(im);
+                m.texture = (int32_t)seen.size() - 1;
+            } else {
+                m.texture = (int32_t)(it - seen.begin());
+            }
+        }
+        f.materials.push_back(m);
+    }
+    if (const Image* im = scene.environment.get()) {
+        auto it = std::find(seen.begin(), seen.end(), im);
+        if (it == seen.end()) {
+            f.textures.push_back({ (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) });
+            f.texels.reserve(f.texels.size() + 3 * im->pixels.size());
+            for (const vec3& p : im->pixels)
+                f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
+            seen.push_back(im);
+            f.environment = (uint32_t)seen.size();
+        } else {
+            f.environment = (uint32_t)(it - seen.begin()) + 1;
+        }
+    }
+    for (const Light& l : scene.lights) {
+        srt_light o {};
+        if (std::holds_alternative<PointLight>(l)) {
+            const PointLight& p = std::get<PointLight>(l);
+            o.type = 0;
+            put3(o.f, p.position), put3(o.f + 3, p.color);
+        } else if (std::holds_alternative<SegmentLight>(l)) {
+            const SegmentLight& s = std::get<SegmentLight>(l);
+            o.type = 1;
+            put3(o.f, s.endpoint0), put3(o.f + 3, s.endpoint1), put3(o.f + 6, s.color0), put3(o.f + 9, s.color1);
+        } else {
+            const ParallelogramLight& p = std::get<ParallelogramLight>(l);
+            o.type = 2;
+            put3(o.f, p.v0), put3(o.f + 3, p.edge01), put3(o.f + 6, p.edge02);
+            put3(o.f + 9, p.color0), put3(o.f + 12, p.color1), put3(o.f + 15, p.color2), put3(o.f + 18, p.color3);
+        }
+        f.lights.push_back(o);
+    }
+}
+
 FlatScene BoundingVolumeHierarchy::flatten(int bfsLevels) const
 {
     const Scene& scene = *m_pScene;
@@ -413,81 +472,66 @@ FlatScene BoundingVolumeHierarchy::flatten(int bfsLevels) const
         o.pad = 0;
     }
 
-    /* materials (one per mesh), distinct textures, lights */
-    std::vector<const Image*> seen;
-    for (const Mesh& mesh : scene.meshes) {
-        srt_material m {};
-        put3(m.kd, mesh.material.kd);
-        put3(m.ks, mesh.material.ks);
-        m.shininess = mesh.material.shininess;
-        m.transparency = mesh.material.transparency;
-        m.texture = -1;
-        if (const Image* im = mesh.material.kdTexture.get()) {
-            auto it = std::find(seen.begin(), seen.end(), im);
-            if (it == seen.end()) {
-                srt_texture t { (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) };
-                f.textures.push_back(t);
-                for (const vec3& p : im->pixels)
-                    f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
-                seen.push_back(im);
-                m.texture = (int32_t)seen.size() - 1;
-            } else {
-                m.texture = (int32_t)(it - seen.begin());
-            }
-        }
-        f.materials.push_back(m);
-    }
-    if (const Image* im = scene.environment.get()) {
-        auto it = std::find(seen.begin(), seen.end(), im);
-        if (it == seen.end()) {
-            f.textures.push_back({ (uint32_t)im->width, (uint32_t)im->height, (uint64_t)(f.texels.size() / 3) });
-            f.texels.reserve(f.texels.size() + 3 * im->pixels.size());
-            for (const vec3& p : im->pixels)
-                f.texels.push_back(p.x), f.texels.push_back(p.y), f.texels.push_back(p.z);
-            seen.push_back(im);
-            f.environment = (uint32_t)seen.size();
-        } else {
-            f.environment = (uint32_t)(it - seen.begin()) + 1;
-        }
-    }
-    for (const Light& l : scene.lights) {
-        srt_light o {};
-        if (std::holds_alternative<PointLight>(l)) {
-            const PointLight& p = std::get<PointLight>(l);
-            o.type = 0;
-            put3(o.f, p.position), put3(o.f + 3, p.color);
-        } else if (std::holds_alternative<SegmentLight>(l)) {
-            const SegmentLight& s = std::get<SegmentLight>(l);
-            o.type = 1;
-            put3(o.f, s.endpoint0), put3(o.f + 3, s.endpoint1), put3(o.f + 6, s.color0), put3(o.f + 9, s.color1);
-        } else {
-            const ParallelogramLight& p = std::get<ParallelogramLight>(l);
-            o.type = 2;
-            put3(o.f, p.v0), put3(o.f + 3, p.edge01), put3(o.f + 6, p.edge02);
-            put3(o.f + 9, p.color0), put3(o.f + 12, p.color1), put3(o.f + 15, p.color2), put3(o.f + 18, p.color3);
-        }
-        f.lights.push_back(o);
-    }
+    packAppearance(scene, f);
     return f;
 }
 
 /* ------------------------------------------------------------------------------------------ BvhInterface */
 
 BvhInterface::BvhInterface(Scene* pScene, const Features& features)
-    : m_impl(new BoundingVolumeHierarchy(pScene, features))
-    , m_pScene(pScene)
+    : m_pScene(pScene)
     , m_gpu(currentDevice())
 {
     srt_device* dev = deviceFor(m_gpu);
-    /* Depth-first node order.  SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead, for builds
-     * of the back end that keep the head of the node array in LDS (SRT_SHADOW_LDS_NODES, off by default). */
-    const char* lv = std::getenv("SRT_EXPERIMENT_BFS_LEVELS");
-    const FlatScene flat = m_impl->flatten(lv ? std::atoi(lv) : 0);
-    const srt_scene_desc d = flat.desc();
-    if (srt_scene_upload(dev, &d, &m_dev) != SRT_OK) {
-        delete m_impl;
-        raise("scene upload failed");
+    const char* hostBuild = std::getenv("SRT_HOST_BUILD");
+    if (features.extra.enableBvhSahBinning || (hostBuild && hostBuild[0] == '1')) {
+        /* the SAH-binned tree's shape depends on the geometry: built and flattened on the host, then uploaded.
+         * Depth-first node order; SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead, for
+         * builds of the back end that keep the head of the node array in LDS (SRT_SHADOW_LDS_NODES, off by default). */
+        m_impl = new BoundingVolumeHierarchy(pScene, features);
+        const char* lv = std::getenv("SRT_EXPERIMENT_BFS_LEVELS");
+        const FlatScene flat = m_impl->flatten(lv ? std::atoi(lv) : 0);
+        const srt_scene_desc d = flat.desc();
+        if (srt_scene_upload(dev, &d, &m_dev) != SRT_OK) {
+            delete m_impl;
+            raise("scene upload failed");
+        }
+        return;
     }
+    /* the reference's median-split tree: the back end builds it on the device from the triangle list */
+    const Scene& scene = *pScene;
+    FlatScene look;
+    packAppearance(scene, look);
+    std::vector<float> verts;
+    std::vector<uint32_t> tris, triMesh, meshTriOff { 0 };
+    size_t nVerts = 0, nTris = 0;
+    for (const Mesh& mesh : scene.meshes)
+        nVerts += mesh.vertices.size(), nTris += mesh.triangles.size();
+    verts.reserve(8 * nVerts), tris.reserve(3 * nTris), triMesh.reserve(nTris);
+    static_assert(sizeof(Vertex) == 32, "Vertex is 8 packed floats");
+    uint32_t base = 0;
+    for (size_t m = 0; m < scene.meshes.size(); ++m) {
+        const Mesh& mesh = scene.meshes[m];
+        const float* v = reinterpret_cast<const float*>(mesh.vertices.data());
+        verts.insert(verts.end(), v, v + 8 * mesh.vertices.size());
+        for (const uvec3& t : mesh.triangles) {
+            tris.push_back(base + t.x), tris.push_back(base + t.y), tris.push_back(base + t.z);
+            triMesh.push_back((uint32_t)m);
+        }
+        base += (uint32_t)mesh.vertices.size();
+        meshTriOff.push_back((uint32_t)triMesh.size());
+    }
+    srt_build_desc b {};
+    b.verts = verts.data(), b.n_verts = (uint32_t)nVerts;
+    b.tris = tris.data(), b.tri_mesh = triMesh.data(), b.n_tris = (uint32_t)nTris;
+    b.mesh_tri_off = meshTriOff.data(), b.n_meshes = (uint32_t)scene.meshes.size();
+    b.materials = look.materials.data(), b.n_materials = (uint32_t)look.materials.size();
+    b.textures = look.textures.data(), b.n_textures = (uint32_t)look.textures.size();
+    b.texels = look.texels.data(), b.n_texels = look.texels.size() / 3;
+    b.lights = look.lights.data(), b.n_lights = (uint32_t)look.lights.size();
+    b.environment = look.environment;
+    if (srt_scene_build(dev, &b, &m_dev) != SRT_OK)
+        raise("scene build failed");
 }
 
 BvhInterface::~BvhInterface()
@@ -496,8 +540,18 @@ BvhInterface::~BvhInterface()
     delete m_impl;
 }
 
-int BvhInterface::numLevels() const { return m_impl->numLevels(); }
-int BvhInterface::numLeaves() const { return m_impl->numLeaves(); }
+int BvhInterface::numLevels() const
+{
+    uint32_t levels = 0;
+    srt_scene_info(m_dev, nullptr, nullptr, &levels, nullptr, nullptr, nullptr);
+    return (int)levels;
+}
+int BvhInterface::numLeaves() const
+{
+    uint32_t leaves = 0;
+    srt_scene_info(m_dev, nullptr, nullptr, nullptr, &leaves, nullptr, nullptr);
+    return (int)leaves;
+}
 srt_device* BvhInterface::device() const { return deviceFor(m_gpu); }
 
 void BvhInterface::intersectBatch(float* rays7, int64_t n, const Features& features, srt_hit* hits, srt_counters* counters, bool referenceTraversal) const

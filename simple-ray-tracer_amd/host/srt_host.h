@@ -282,13 +282,15 @@ public:
     void intersectBatch(float* rays7, int64_t n, const Features& features, srt_hit* hits, srt_counters* counters = nullptr,
                         bool referenceTraversal = false) const;
 
-    const BoundingVolumeHierarchy& impl() const { return *m_impl; }
+    /* The host-side node table: only present when the tree was built on the host (SAH binning, or SRT_HOST_BUILD=1 in
+     * the environment); the median-split tree is built on the device. */
+    const BoundingVolumeHierarchy* impl() const { return m_impl; }
     const Scene& scene() const { return *m_pScene; }
     srt_scene* deviceScene() const { return m_dev; }
     srt_device* device() const;
 
 private:
-    BoundingVolumeHierarchy* m_impl;
+    BoundingVolumeHierarchy* m_impl = nullptr;
     Scene* m_pScene;
     srt_scene* m_dev = nullptr;
     int m_gpu = 0;

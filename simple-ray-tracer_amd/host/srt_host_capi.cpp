@@ -346,6 +346,18 @@ int srth_probe_gather(const srth_bvh* b, uint64_t window_bytes, uint32_t loads_p
     return 0;
 }
 
+/* Sizes and arrays of the scene as it sits on the device (built there, or uploaded): sizes4 = nodes, triangles,
+ * levels, leaves; arrays may be NULL. */
+int srth_bvh_download(const srth_bvh* b, uint32_t* sizes4, void* nodes, void* tris, void* attrs, uint32_t* sceneOrder, float* rootBox6, uint32_t* rootRef)
+{
+    if (srt_scene_info(b->bvh->deviceScene(), sizes4, sizes4 + 1, sizes4 + 2, sizes4 + 3, rootRef, rootBox6) != SRT_OK
+        || srt_scene_download(b->bvh->deviceScene(), (srt_node*)nodes, (srt_tri*)tris, (srt_tri_attr*)attrs, sceneOrder) != SRT_OK) {
+        g_err = srt_last_error();
+        return -1;
+    }
+    return 0;
+}
+
 int srth_read_counters(const srth_bvh* b, void* stream, srt_counters* out, int reset)
 {
     if (srt_device_read_counters(b->bvh->device(), stream, out, reset) != SRT_OK) {
