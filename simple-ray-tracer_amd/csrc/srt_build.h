@@ -23,6 +23,8 @@
  * mirror's BoundingVolumeHierarchy + flatten(0) produce (depth-first numbering, right child next to its parent).
  */
 
+#include "srt_sort.h"
+
 struct BuildNode {
     uint32_t left, right; /* child references, final encoding */
     uint32_t level;       /* of this node (root = 0) */
@@ -202,6 +204,16 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     using namespace srt_build;
     if (!dev || !desc || !out)
         return fail(SRT_ERR_INVALID, "srt_scene_build: null argument");
+    const bool trace = getenv("SRT_BUILD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char* what) {
+        if (trace) {
+            const double t = now();
+            fprintf(stderr, "[srt_scene_build] %-28s %7.2f ms\n", what, t - t_prev);
+            t_prev = t;
+        }
+    };
     *out = nullptr;
     const uint32_t n = desc->n_tris;
     if (n > SRT_MAX_TRIS)
@@ -239,7 +251,8 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
         if (desc->lights[i].type > 2)
             return fail(SRT_ERR_INVALID, "light %u: unknown type %u", i, desc->lights[i].type);
 
-    /* order: given, or the reference's nested sorts on centroid keys */
+    lap("argument checks");
+    /* order: given, or worked out below (on the device; on the host if the device gives up) */
     std::vector<uint32_t> order;
     if (desc->order) {
         std::vector<uint8_t> seen(n, 0);
@@ -249,7 +262,8 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
             seen[desc->order[k]] = 1;
         }
         order.assign(desc->order, desc->order + n);
-    } else {
+    }
+    auto host_order = [&]() {
         order.resize(n);
         std::vector<float> centroid[3];
         for (auto& c : centroid)
@@ -261,8 +275,7 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
                 centroid[k][t] = ((a[k] + b[k]) + c[k]) / 3.0f; /* getMedian, reference :37-45 */
         }
         order_rec(order, centroid, 0, n, 0, 0, n >= 4096 ? 4 : 0);
-    }
-
+    };
     /* shape */
     std::vector<BuildNode> shape;
     std::vector<std::vector<uint32_t>> by_level;
@@ -279,6 +292,7 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     }
     level_start.push_back((uint32_t)level_nodes.size());
 
+    lap("shape");
     HIPCHK(hipSetDevice(dev->gpu));
     srt_scene* s = new srt_scene();
     s->dev = dev;
@@ -313,7 +327,23 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     if (rc == SRT_OK) rc = temp_upload(desc->tris, (size_t)n * 12, &d_tris3);
     if (rc == SRT_OK) rc = temp_upload(desc->tri_mesh, (size_t)n * 4, &d_tri_mesh);
     if (rc == SRT_OK) rc = temp_upload(desc->n_meshes ? desc->mesh_tri_off : zero_off, ((size_t)desc->n_meshes + 1) * 4, &d_mesh_off);
-    if (rc == SRT_OK) rc = temp_upload(order.data(), (size_t)n * 4, &d_order);
+    lap("uploads of the triangle list");
+    d_order = nullptr;
+    const char* where = getenv("SRT_BUILD_SORT"); /* "host": skip the device sort (A/B and fallback testing) */
+    if (rc == SRT_OK && order.empty() && n >= 2 && !(where && !strcmp(where, "host"))) {
+        bool fell_back = false;
+        uint32_t* dev_order = nullptr;
+        rc = device_order((const float*)d_verts, (const uint32_t*)d_tris3, n, (uint32_t)by_level.size(), temp, &dev_order, &fell_back);
+        if (rc == SRT_OK && !fell_back)
+            d_order = dev_order;
+        lap(fell_back ? "device sort (gave up)" : "device sort");
+    }
+    if (rc == SRT_OK && !d_order) {
+        if (order.empty())
+            host_order();
+        lap("host sort");
+        rc = temp_upload(order.data(), (size_t)n * 4, &d_order);
+    }
     if (rc == SRT_OK) rc = temp_upload(shape.data(), shape.size() * sizeof(BuildNode), &d_shape);
     if (rc == SRT_OK) rc = temp_upload(level_nodes.data(), level_nodes.size() * 4, &d_level_nodes);
     if (rc == SRT_OK) rc = temp_upload(zeros, sizeof zeros, &d_result); /* [0]: some box is outside the fast ranges; [1..6]: the root box */
@@ -335,6 +365,7 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
         srt_scene_destroy(s);
         return rc;
     }
+    lap("allocations and uploads");
     uint32_t* d_not_fast = (uint32_t*)d_result;
     float* d_root_box = (float*)d_result + 1;
     if (n)
@@ -352,6 +383,7 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     hipError_t e = hipGetLastError();
     if (e == hipSuccess)
         e = hipMemcpy(result, d_result, sizeof result, hipMemcpyDeviceToHost); /* also waits for the kernels */
+    lap("kernels");
     cleanup();
     if (e != hipSuccess) {
         srt_scene_destroy(s);
@@ -380,6 +412,7 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     fast = fast && root_box[0] <= root_box[3] && root_box[1] <= root_box[4] && root_box[2] <= root_box[5];
     v.fast_boxes = fast ? 1u : 0u;
     rc = scene_grids(dev, s);
+    lap("frees and launch shapes");
     if (rc != SRT_OK) {
         srt_scene_destroy(s);
         return rc;

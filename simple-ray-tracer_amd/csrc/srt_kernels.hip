@@ -42,6 +42,8 @@
 #include <cstring>
 #include <mutex>
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>

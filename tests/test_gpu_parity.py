@@ -142,6 +142,63 @@ def test_device_built_scene_equals_host_built(orc, scenes, gpu, name):
         assert got[key].tobytes() == want[key].tobytes(), key
 
 
+def _soup_scene(orc, n, seed, keys_x=None):
+    """n small triangles on a coarse coordinate grid (many exactly equal centroid coordinates on every axis).  With
+    keys_x the three corners of triangle i share x = keys_x[i], so its centroid's x is exactly that number."""
+    rng = np.random.default_rng(seed)
+    d = orc.empty_scene()
+    base = rng.integers(0, 24, (n, 1, 3)).astype(np.float32)
+    corners = base + rng.integers(0, 4, (n, 3, 3)).astype(np.float32) * np.float32(0.25)
+    if keys_x is not None:
+        corners[:, :, 0] = np.asarray(keys_x, np.float32)[:, None]
+    v = np.zeros((3 * n, 8), np.float32)
+    v[:, :3], v[:, 5] = corners.reshape(-1, 3), 1.0
+    d["verts"], d["tris"] = v, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    d["mesh_vert_off"], d["mesh_tri_off"] = np.array([0, 3 * n], np.uint32), np.array([0, n], np.uint32)
+    d["materials"] = np.array([[1, 1, 1, 0.2, 0.2, 0.2, 10.0, 1.0]], np.float32)
+    d["mesh_tex"] = np.array([-1], np.int32)
+    return d
+
+
+def _assert_device_build_equals_host_build(d):
+    scene = srt.Scene.from_arrays(d)
+    got = srt.Bvh(scene, srt.F_ACCEL).download()
+    hb = srt.HostBvh(scene, srt.F_ACCEL)
+    want = hb.flatten(0)
+    assert (got["num_levels"], got["num_leaves"]) == (hb.num_levels, hb.num_leaves)
+    for key in ("nodes", "tris", "attrs", "scene_order"):
+        assert got[key].tobytes() == want[key].tobytes(), key
+
+
+@pytest.mark.parametrize("n", [2, 3, 16, 17, 18, 33, 100, 1023, 1024, 1025, 1026, 2047, 2048, 2049, 3073, 5000, 70001, 300000])
+def test_device_sort_reproduces_std_sort_order(orc, gpu, n, monkeypatch, capfd):
+    """The device-side sort leaves equal keys in the order libstdc++'s introsort leaves them, for range sizes on both
+    sides of every threshold it has (16: insertion sort only; 1024: the tile kernel's limit; 2048: two tiles)."""
+    monkeypatch.setenv("SRT_BUILD_TRACE", "1")
+    _assert_device_build_equals_host_build(_soup_scene(orc, n, 100 + n))
+    err = capfd.readouterr().err
+    assert "device sort" in err and "gave up" not in err and "host sort" not in err
+
+
+@pytest.mark.parametrize("n", [600, 5000])
+def test_device_sort_hands_depth_limit_cases_to_the_host(orc, gpu, n, monkeypatch, capfd):
+    """Keys on which std::sort exhausts its depth limit and heapsorts (tests/golden/make_sort_killer.py): the device
+    sort does not reproduce heapsort; it reports the case and the build sorts on the host, with the same result."""
+    keys = np.load(os.path.join(os.path.dirname(__file__), "golden", "sort_killer.npz"))[f"keys{n}"]
+    monkeypatch.setenv("SRT_BUILD_TRACE", "1")
+    _assert_device_build_equals_host_build(_soup_scene(orc, n, 7, keys_x=keys))
+    err = capfd.readouterr().err
+    assert "device sort (gave up)" in err and "host sort" in err
+
+
+def test_build_with_host_sort(orc, scenes, gpu, monkeypatch, capfd):
+    monkeypatch.setenv("SRT_BUILD_SORT", "host")
+    monkeypatch.setenv("SRT_BUILD_TRACE", "1")
+    _assert_device_build_equals_host_build(scenes("teapot"))
+    err = capfd.readouterr().err
+    assert "host sort" in err and "device sort" not in err
+
+
 def test_empty_scene_and_empty_batch(orc, gpu):
     d = orc.empty_scene()
     gb = srt.Bvh(srt.Scene.from_arrays(d))
