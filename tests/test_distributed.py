@@ -70,7 +70,8 @@ def test_three_ranks_one_without_tiles(tmp_path):
     z = _run_ranks(tmp_path, 3, "2", "2")
     assert np.array_equal(z["frame"].view(np.uint32), z["whole"].view(np.uint32))
     counts = z["counts"]  # [rank, frame]
-    assert counts.shape == (3, 2) and (counts[2] == 0).all() and (counts[:2] > 0).all()
+    # (how ranks 0 and 1 share the tiles between them depends on the machine's load: either may draw them all)
+    assert counts.shape == (3, 2) and (counts[2] == 0).all()
     assert (counts.sum(0) == int(z["n_tiles"])).all()
     assert (z["orders"] == z["orders"][0]).all()
 
