@@ -9,7 +9,48 @@ import json
 import sqlite3
 import sys
 
+def derive(per_launch, out=sys.stdout):
+    """Ratios per traversal / shading kernel from the per-launch counter sums {(kernel, counter): value}.
+    One XCD's GRBM_GUI_ACTIVE is the kernel's duration in shader clocks; the counter is summed over the 8 XCDs."""
+    kernels = sorted({k for k, _ in per_launch if "k_trace" in k or "k_shade" in k or "k_resolve" in k})
+    if not kernels:
+        return
+    print(file=out)
+    print("# derived, per kernel: clocks = GRBM_GUI_ACTIVE / 8 XCDs; per-CU figures divide by 256 CUs", file=out)
+    print("#   lanes/VALU inst = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU; TA busy = TA_TA_BUSY_sum / (clocks * 256);", file=out)
+    print("#   VALU inst/clk/CU = SQ_INSTS_VALU / (clocks * 256); L1 lookups/clk/CU = TCP_TOTAL_CACHE_ACCESSES_sum / (clocks * 256);", file=out)
+    print("#   VMEM rd inst/clk/CU = SQ_INSTS_VMEM_RD / (clocks * 256); L2 hit = TCC_HIT / (TCC_HIT + TCC_MISS)", file=out)
+    for k in kernels:
+        g = lambda c: per_launch.get((k, c))
+        clocks = g("GRBM_GUI_ACTIVE") / 8 if g("GRBM_GUI_ACTIVE") else None
+        cells = []
+        if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+            cells.append(f"lanes/VALU inst {g('SQ_THREAD_CYCLES_VALU') / g('SQ_ACTIVE_INST_VALU'):5.1f}")
+        if clocks:
+            cu = clocks * 256
+            for label, c in (("TA busy", "TA_TA_BUSY_sum"), ("VALU inst/clk/CU", "SQ_INSTS_VALU"), ("SALU inst/clk/CU", "SQ_INSTS_SALU"),
+                             ("VMEM rd inst/clk/CU", "SQ_INSTS_VMEM_RD"), ("L1 lookups/clk/CU", "TCP_TOTAL_CACHE_ACCESSES_sum")):
+                if g(c) is not None:
+                    cells.append(f"{label} {g(c) / cu:6.3f}")
+        if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+            cells.append(f"L2 hit {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):6.4f}")
+        print(f"{k:40s} " + "; ".join(cells), file=out)
+
+
+if sys.argv[1] == "--derive":  # append the derived table to a summary written earlier
+    table = {}
+    for line in open(sys.argv[2]):
+        if " per_launch=" in line and " launches=" in line:
+            left, value = line.rsplit(" per_launch=", 1)
+            left = left.rsplit(" launches=", 1)[0].rstrip()
+            kernel, counter = left.rsplit(None, 1)
+            table[(kernel.strip(), counter)] = float(value)
+    derive(table, open(sys.argv[2], "a"))
+    sys.exit(0)
+
+
 base, title = sys.argv[1], sys.argv[2]
+everything = {}
 print(f"# {title}")
 try:
     print("# kernel-source-sha256: " + open(base + "/source_hash.txt").read().strip())
@@ -44,3 +85,5 @@ for d in sorted(glob.glob(base + "/pmc_*/")):
         n[(k, ctr)] += 1
     for k, v in sorted(agg.items()):
         print(f"{k[0]:40s} {k[1]:30s} launches={n[k]:2d} per_launch={v / n[k]:.5g}")
+        everything[k] = v / n[k]
+derive(everything)

@@ -1,8 +1,10 @@
 #!/bin/bash
 # Profiles bench.py on the GPU box: one rocprofv3 --kernel-trace --stats run, then one --pmc run per counter group
 # (a group holds what one pass can collect).  usage: tools/profile.sh <name> [bench.py arguments]
-# Output: gpurun_out/prof_<name>/{trace,pmc_*}; condense with profiles/summarize.py.
+# Output: gpurun_out/prof_<name>/{summary.txt,bench_line.json,source_hash.txt}: the raw rocprofv3 output is condensed by
+# profiles/summarize.py on the box and deleted there (it can exceed what gpurun copies back); KEEP_RAW=1 keeps it.
 R=$GRAFT_REPO_ROOT
+NAME=$1
 O=$R/gpurun_out/prof_$1
 shift
 mkdir -p $O
@@ -23,4 +25,7 @@ run_group sq3 SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU S
 run_group tc1 TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum &&
 run_group ta1 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum GRBM_GUI_ACTIVE &&
 run_group fetch FETCH_SIZE &&
-run_group write WRITE_SIZE
+run_group write WRITE_SIZE || exit 1
+python3 $R/profiles/summarize.py $O "$NAME: bench.py $*" > $O/summary.txt || exit 1
+[ -n "$KEEP_RAW" ] || rm -rf $O/trace $O/pmc_*/
+echo "summary written"
