@@ -249,8 +249,9 @@ void srt_scene_destroy(srt_scene* scene);
  * Scene's meshes (reference src/bounding_volume_hierarchy.cpp:14-94, the median-split builder; the SAH variant is built
  * on the host and goes through srt_scene_upload).  Triangle records and node boxes are computed by kernels; the node
  * numbering follows from the triangle count; the left-to-right order of the triangles (the reference's nested
- * std::sort calls, tie order included) is taken from `order` or, when that is NULL, worked out by the library on
- * centroid keys.  The resulting arrays equal, bit for bit, what the host mirror's builder + flatten(0) upload
+ * std::sort calls, tie order included) is taken from `order` or, when that is NULL, worked out by the library: on the
+ * device, by kernels that reproduce libstdc++'s introsort step for step on centroid keys, or by std::sort itself on the
+ * host for the inputs those kernels hand back (a range that exhausts introsort's depth limit, a NaN coordinate).  The resulting arrays equal, bit for bit, what the host mirror's builder + flatten(0) upload
  * (srt_scene_download reads them back). */
 typedef struct srt_build_desc {
     const float* verts;        /* 8 floats per vertex (position, normal, texCoord: struct Vertex, reference
