@@ -707,9 +707,8 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
                     atomicAdd(a3 + 1, thr.y * e.y);
                     atomicAdd(a3 + 2, thr.z * e.z);
                 } else {
-                    a3[0] = a3[0] + thr.x * e.x;
-                    a3[1] = a3[1] + thr.y * e.y;
-                    a3[2] = a3[2] + thr.z * e.z;
+                    /* the value of the sample's deepest level, folded into the levels above it by sample_value */
+                    a3[0] = e.x, a3[1] = e.y, a3[2] = e.z;
                 }
             }
         }
@@ -1095,12 +1094,17 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     flush_counters(cnt, 0, nShadow, 0, st);
 }
 
-/* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).  The
- * reference's Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is accumulated front to back as
- * Lo_0 + (ks_0) * Lo_1 + (ks_0 * ks_1) * Lo_2 + ...; identical for paths of at most one bounce. */
+/* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).
+ * Reflections: the reference returns Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)), innermost product first.  A sample has one
+ * ray per depth here, so acc[sample] holds the value of the deepest level reached so far, and a hit that sends on a
+ * reflection ray parks its (Lo, ks) in `chain` (level-major: 6 floats at (level * n_samples + sample)), counts the
+ * level in `nlev` and leaves zero in acc - the value of a reflection ray that hits nothing.  sample_value folds the
+ * parked levels from the deepest up, with the reference's operations in the reference's order.
+ * Transparency: a sample's rays form a binary tree instead; their shares are weighted by the product of the factors
+ * on the way (thr) and added front to back (within rounding of the reference's nested sums). */
 __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count, const float4* cur_paths,
-                                                       float4* next_paths, uint32_t* next_count, float* acc, const unsigned char* vis,
-                                                       uint32_t shadows_per_hit, DevCounters* cnt)
+                                                       float4* next_paths, uint32_t* next_count, float* acc, float* chain, unsigned char* nlev,
+                                                       const unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt)
 {
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShaded = 0;
@@ -1133,16 +1137,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             if (!black) {
                 if (depth == 0) {
                     a3[0] = keep * Lo.x, a3[1] = keep * Lo.y, a3[2] = keep * Lo.z;
-                } else if (seeThrough) {
+                } else if (!seeThrough) {
+                    a3[0] = Lo.x, a3[1] = Lo.y, a3[2] = Lo.z;
+                } else {
                     /* several rays of one sample can be at the same depth: their shares are added atomically
                      * (the order of the additions, hence the last bits of the sum, may vary between runs) */
                     atomicAdd(a3 + 0, own.x * Lo.x);
                     atomicAdd(a3 + 1, own.y * Lo.y);
                     atomicAdd(a3 + 2, own.z * Lo.z);
-                } else {
-                    a3[0] = a3[0] + thr.x * Lo.x;
-                    a3[1] = a3[1] + thr.y * Lo.y;
-                    a3[2] = a3[2] + thr.z * Lo.z;
                 }
             }
             if (!black && (rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f)) {
@@ -1154,6 +1156,12 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
                 ro = (o + d * T) + (offset * rd);
                 nthr = own * sf.ks;
                 spawn = true;
+                if (!seeThrough) {
+                    float* c6 = chain + ((size_t)depth * rp.n_samples + sample) * 6;
+                    c6[0] = Lo.x, c6[1] = Lo.y, c6[2] = Lo.z, c6[3] = sf.ks.x, c6[4] = sf.ks.y, c6[5] = sf.ks.z;
+                    nlev[sample] = (unsigned char)(depth + 1);
+                    a3[0] = a3[1] = a3[2] = 0.0f;
+                }
             }
             if (!black && seeThrough && tr < 1.0f) {
                 /* the ray continued behind the surface, reference src/render.cpp:113 */
@@ -1181,8 +1189,22 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
     flush_counters(cnt, 0, 0, nShaded, st);
 }
 
+/* getFinalColor's return value for one sample: the deepest level's value, folded into the levels that sent on a
+ * reflection ray (`Lo += ks * getFinalColor(...)`, reference src/render.cpp:109), innermost first. */
+SRT_DI f3 sample_value(const RenderDev& rp, const float* acc, const float* chain, const unsigned char* nlev, uint32_t s)
+{
+    f3 v = mk3(acc[3ull * s], acc[3ull * s + 1], acc[3ull * s + 2]);
+    if (chain) {
+        for (int level = (int)nlev[s] - 1; level >= 0; --level) {
+            const float* c6 = chain + ((size_t)level * rp.n_samples + s) * 6;
+            v = mk3(c6[0] + c6[3] * v.x, c6[1] + c6[4] * v.y, c6[2] + c6[5] * v.z);
+        }
+    }
+    return v;
+}
+
 /* Pixel value from its samples (reference src/render.cpp:213-217) stored at Screen::setPixel's position. */
-__global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float* acc)
+__global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float* acc, const float* chain, const unsigned char* nlev)
 {
     const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
     for (uint32_t p = blockIdx.x * SRT_BLOCK + threadIdx.x; p < n_px; p += gridDim.x * SRT_BLOCK) {
@@ -1192,17 +1214,15 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float
         if (rp.lens_mode) {
             /* Lo += getFinalColor(...) / samples, reference src/render.cpp:158,175 (black with zero samples) */
             for (int s = 0; s < rp.lens.samples; ++s) {
-                const float* a = acc + 3ull * (first + (uint32_t)s);
-                c = c + mk3(a[0], a[1], a[2]) / (float)rp.lens.samples;
+                c = c + sample_value(rp, acc, chain, nlev, first + (uint32_t)s) / (float)rp.lens.samples;
             }
         } else if (rp.features & SRT_F_MULTISAMPLE) {
             for (int s = 0; s < rp.S; ++s) {
-                const float* a = acc + 3ull * (first + (uint32_t)s);
-                c = c + mk3(a[0], a[1], a[2]);
+                c = c + sample_value(rp, acc, chain, nlev, first + (uint32_t)s);
             }
             c = c / (float)rp.S;
         } else {
-            c = mk3(acc[3ull * first], acc[3ull * first + 1], acc[3ull * first + 2]);
+            c = sample_value(rp, acc, chain, nlev, first);
         }
         float* o = rp.out_rgb + 3 * out_index(rp, px, py);
         o[0] = c.x, o[1] = c.y, o[2] = c.z;
@@ -1429,7 +1449,7 @@ struct srt_device {
     DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family, plus one for srt_intersect_batch */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
     unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
-    DevBuf acc, hq_slot, hq_t, hq_tri, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
+    DevBuf acc, chain, nlev, hq_slot, hq_t, hq_tri, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
     hipEvent_t ev[SRT_MAX_EVENTS];
     int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
     int n_ev = 0;
@@ -1534,7 +1554,7 @@ void srt_device_destroy(srt_device* d)
         return;
     (void)hipSetDevice(d->gpu);
     (void)hipDeviceSynchronize();
-    DevBuf* bufs[] = { &d->acc, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
+    DevBuf* bufs[] = { &d->acc, &d->chain, &d->nlev, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
         &d->out_t, &d->io_a, &d->io_b };
     for (DevBuf* b : bufs)
         b->release();
@@ -1827,6 +1847,8 @@ static uint32_t shadows_per_hit(const srt_scene* sc, uint32_t features)
  * from buffers the device handle grows on demand, srt_render_noalloc from the static scratch array. */
 struct Work {
     float* acc = nullptr;            /* 3 floats per sample */
+    float* chain = nullptr;          /* reflections without transparency: 6 floats per (level < max_depth, sample), see k_shade */
+    unsigned char* nlev = nullptr;   /* ... and the number of levels a sample has parked there */
     HitQ hq {};                      /* one entry per sample (more with transparency) */
     unsigned char* vis = nullptr;    /* one byte per (hit, shadow query) */
     float4* path[2] = { nullptr, nullptr }; /* 3 float4 per queued path ray; only with reflections / transparency */
@@ -1859,12 +1881,20 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
     HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 32 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
+    const bool chained = (rp.features & SRT_F_RECURSIVE) && !(rp.features & SRT_F_TRANSPARENCY) && rp.max_depth > 0;
+    float* chain = chained ? wk.chain : nullptr;
+    unsigned char* nlev = chained ? wk.nlev : nullptr;
+    if (chained) {
+        if (!chain || !nlev)
+            return fail(SRT_ERR_INVALID, "reflections need the per-level buffers");
+        HIPCHK(hipMemsetAsync(nlev, 0, n, st));
+    }
     if (rp.lens_mode && rp.lens.samples == 0) {
         /* motion blur / depth of field with zero samples: the reference's loops do not run and the pixel stays black */
         const uint32_t npx = (uint32_t)rp.tw * (uint32_t)rp.th;
         int gr = (int)((npx + SRT_BLOCK - 1) / SRT_BLOCK);
         if (gr > d->n_cu * 8) gr = d->n_cu * 8;
-        hipLaunchKernelGGL(k_resolve, dim3(gr), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc);
+        hipLaunchKernelGGL(k_resolve, dim3(gr), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
         HIPCHK(hipGetLastError());
         return SRT_OK;
     }
@@ -1882,7 +1912,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
-            acc, (const unsigned char*)vis, sph, d->counters + 2);
+            acc, chain, nlev, (const unsigned char*)vis, sph, d->counters + 2);
         if (depth == last_depth)
             break;
         if (branching) {
@@ -1918,7 +1948,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
     int g_res = (int)((n_px + SRT_BLOCK - 1) / SRT_BLOCK);
     if (g_res > d->n_cu * 8) g_res = d->n_cu * 8;
-    hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc);
+    hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
     mark(d, st, -1, timing);
     HIPCHK(hipGetLastError());
     return SRT_OK;
@@ -1956,7 +1986,7 @@ static int dispatch_render(srt_device* d, srt_scene* sc, const RenderDev& rp, ui
 }
 
 /* Work memory out of the device handle's growable buffers, sized for n samples. */
-static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t features, Work* wk)
+static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t features, int32_t max_depth, Work* wk)
 {
     const uint32_t sph = shadows_per_hit(sc, features);
     int rc = d->acc.reserve((size_t)n * 12);
@@ -1971,9 +2001,14 @@ static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t featur
         rc = d->path[0].reserve((size_t)n * per);
         if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
     }
+    if (rc == SRT_OK && (features & SRT_F_RECURSIVE) && !(features & SRT_F_TRANSPARENCY) && max_depth > 0) {
+        rc = d->chain.reserve((size_t)n * 24 * (size_t)max_depth);
+        if (rc == SRT_OK) rc = d->nlev.reserve(n);
+    }
     if (rc != SRT_OK)
         return rc;
     wk->acc = (float*)d->acc.p;
+    wk->chain = (float*)d->chain.p, wk->nlev = (unsigned char*)d->nlev.p;
     wk->hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
     wk->vis = (unsigned char*)d->vis.p;
     wk->path[0] = (float4*)d->path[0].p, wk->path[1] = (float4*)d->path[1].p;
@@ -2050,7 +2085,7 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
     HIPCHK(hipSetDevice(d->gpu));
     hipStream_t st = (hipStream_t)stream;
     Work wk;
-    rc = handle_work(d, sc, rp.n_samples, p->features, &wk);
+    rc = handle_work(d, sc, rp.n_samples, p->features, rp.max_depth, &wk);
     if (rc != SRT_OK)
         return rc;
     const size_t out_px = (size_t)out->out_width * out->out_height;
@@ -2123,6 +2158,8 @@ int srt_render_noalloc(srt_device* d, srt_scene* sc, const srt_render_params* p,
     if (paths) {
         wk.path[0] = (float4*)carve((size_t)n * 48);
         wk.path[1] = (float4*)carve((size_t)n * 48);
+        wk.chain = (float*)carve((size_t)n * 24 * (size_t)(rp.max_depth > 0 ? rp.max_depth : 0));
+        wk.nlev = carve(n);
     }
     if (off > (size_t)SRT_NOALLOC_SCRATCH_BYTES)
         return fail(SRT_ERR_INVALID, "srt_render_noalloc: the rectangle's %u sample slots need %zu bytes of work memory, the fixed scratch area holds %zu: "
@@ -2193,7 +2230,7 @@ int srt_final_color_batch(srt_device* d, srt_scene* sc, const float* rays7, int6
     int rc = d->io_a.reserve((size_t)n * 28);
     if (rc == SRT_OK) rc = d->io_b.reserve((size_t)n * 12);
     Work wk;
-    if (rc == SRT_OK) rc = handle_work(d, sc, (uint32_t)n, features, &wk);
+    if (rc == SRT_OK) rc = handle_work(d, sc, (uint32_t)n, features, max_depth, &wk);
     if (rc != SRT_OK)
         return rc;
     HIPCHK(hipMemcpy(d->io_a.p, rays7, (size_t)n * 28, hipMemcpyHostToDevice));

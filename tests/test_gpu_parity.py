@@ -280,6 +280,23 @@ def test_reflection_depth(orc, pair, max_depth):
     assert got["counters"]["path_rays"] == want["counters"]["path_rays"]
 
 
+@pytest.mark.parametrize("name,extra", [("monkey", 0), ("teapot", srt.F_NORMAL_INTERP), ("cornell", 0), ("cube_textured", srt.F_TEXTURE | srt.F_NORMAL_INTERP)])
+def test_reflection_sum_in_reference_order(orc, pair, name, extra):
+    """Lo_0 + ks_0 * (Lo_1 + ks_1 * (...)) is evaluated innermost product first, as the reference's recursion does
+    (src/render.cpp:109).  Without the shading switch a hit's own colour is its kd - no powf anywhere - so every
+    operation is correctly rounded on both sides and the frames must agree bit for bit, multi-bounce pixels included."""
+    ob, gb = pair(name)
+    feat = srt.F_ACCEL | srt.F_RECURSIVE | srt.F_MISS_CULL | extra
+    want = ob.render(orc.make_camera(96, 72), feat, max_depth=5)
+    got = gb.render(srt.make_camera(96, 72), feat, max_depth=5)
+    assert_bits_equal(got["rgb"], want["rgb"], name + " reflection sums")
+    if name in ("monkey", "teapot"):  # concave and specular all over: some pixels see more than one bounce
+        assert (ob.render(orc.make_camera(96, 72), feat, max_depth=1)["rgb"] != want["rgb"]).any()
+    ms = srt.F_MULTISAMPLE
+    assert_bits_equal(gb.render(srt.make_camera(40, 30), feat | ms, nsx=2, nsy=2, max_depth=5)["rgb"],
+                      ob.render(orc.make_camera(40, 30), feat | ms, nsx=2, nsy=2, max_depth=5)["rgb"], name + " 2x2")
+
+
 @pytest.mark.parametrize("name", ["cornell_parallelogram", "cube"])
 def test_soft_shadows(orc, pair, name):
     # parallelogram light (10 x 10 samples) and segment light (100 samples); both sides draw their samples
