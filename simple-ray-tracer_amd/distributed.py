@@ -107,6 +107,13 @@ class FrameTiler:
             x0, y0, x1, y1 = self.rects[t]
             self.frame[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]
 
+    def _settle(self):
+        """Waits until the copies and transfers that read this rank's tile buffer have run: they are ordered on the
+        current stream, but the next frame's tiles may be rendered on other streams, which would otherwise be free
+        to overwrite a slot that is still being read."""
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()
+
     def gather(self, k):
         """Finished tiles of every rank into rank 0's frame (Screen layout: top row first)."""
         t0 = time.perf_counter()
@@ -116,6 +123,7 @@ class FrameTiler:
                 self.frame.copy_(self.tiles[0])
             else:
                 self._place(self.ids[:k].tolist(), self.tiles)
+            self._settle()
             self.step += 1
             return
         n = self.n_tiles
@@ -151,6 +159,7 @@ class FrameTiler:
                 self._place(host[r, 1:1 + len(b)].tolist(), b)
         elif k:
             dist.isend(self.tiles[:k].contiguous(), dst=0).wait()
+        self._settle()
         if os.environ.get("SRT_BENCH_DEBUG"):
             t3 = time.perf_counter()
             print(f"[rank {self.rank}] gather: wait for tiles {1e3 * (t1 - t0):.1f} ms, tile ids {1e3 * (t2 - t1):.1f} ms, "
