@@ -934,9 +934,13 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
         const bool c1 = two && tri_plane(a1, w.o, w.d, nt1) && nt1 <= T;
         bool in0 = false, in1 = false;
         if (c0 | c1) {
-            /* one block without branches: the ten quarters are requested together */
-            const bool i0 = tri_inside(r0, w.o, w.d, nt0), i1 = tri_inside(r1, w.o, w.d, nt1);
-            in0 = c0 & i0, in1 = c1 & i1;
+            if (__any(c1)) {
+                /* one block without branches: the ten quarters are requested together */
+                const bool i0 = tri_inside(r0, w.o, w.d, nt0), i1 = tri_inside(r1, w.o, w.d, nt1);
+                in0 = c0 & i0, in1 = c1 & i1;
+            } else {
+                in0 = tri_inside(r0, w.o, w.d, nt0); /* no lane of the wave needs a second triangle (one-triangle leaves) */
+            }
         }
         if (in0)
             T = nt0, hit = true;

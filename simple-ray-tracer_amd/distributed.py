@@ -120,10 +120,10 @@ class FrameTiler:
         self._measure(k)  # also waits for this rank's tiles, whatever streams they were rendered on
         if self.world == 1:
             if self.n_tiles == 1 and (self.tw, self.th) == (self.W, self.H):
-                self.frame.copy_(self.tiles[0])
+                self.frame.copy_(self.tiles[0])  # one tile: rendered on the current stream, which orders the copy
             else:
                 self._place(self.ids[:k].tolist(), self.tiles)
-            self._settle()
+                self._settle()
             self.step += 1
             return
         n = self.n_tiles
