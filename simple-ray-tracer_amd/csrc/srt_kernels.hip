@@ -991,13 +991,20 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
      * long queries simply draw fewer chunks: with a fixed stride instead, the slowest wave's share decided the
      * launch time (measured 220 -> 200 ms on the dragon frame). */
     const unsigned long long first_shared = (unsigned long long)gridDim.x * SRT_SHADOW_BLOCK;
+    /* chunk, used and dry are the same in all lanes of a wave; reading them through readfirstlane tells the compiler
+     * so, and the refill conditions and the loop's exit become scalar branches instead of exec-mask bookkeeping
+     * in every trip */
+    auto uniform = [](unsigned long long v) {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
     auto grab = [&]() {
         unsigned long long base = 0;
         if (lane == 0)
             base = atomicAdd(next_chunk, 64ull);
-        return first_shared + (unsigned long long)__shfl((long long)base, 0, 64);
+        return first_shared + uniform(base); /* lane 0 is the first active lane: no lane leaves the loop before the wave does */
     };
-    unsigned long long chunk = (unsigned long long)blockIdx.x * SRT_SHADOW_BLOCK + (threadIdx.x & ~63u); /* wave-uniform */
+    unsigned long long chunk = uniform((unsigned long long)blockIdx.x * SRT_SHADOW_BLOCK + (threadIdx.x & ~63u));
     bool dry = false;                                                                              /* the items have run out */
     uint32_t used = 0; /* items taken from the current chunk */
     Walk w;
