@@ -102,7 +102,17 @@ class FrameTiler:
         self.order = sorted(range(self.n_tiles), key=lambda i: (-cost[i], i))
 
     def _place(self, ids, tiles):
-        H, th = self.H, self.th
+        H, W, th, tw = self.H, self.W, self.th, self.tw
+        if not ids:
+            return
+        if H % th == 0 and W % tw == 0:
+            # whole tiles only: one indexed copy for all of a rank's tiles instead of one small copy per tile
+            nx = W // tw
+            t = torch.as_tensor(ids, dtype=torch.int64, device=self.frame.device)
+            col = t % nx
+            row = (H // th - 1) - t // nx  # tile rows count from the bottom of the frame, frame rows from the top
+            self.frame.view(H // th, th, nx, tw, 3)[row, :, col] = tiles[:len(ids)]
+            return
         for j, t in enumerate(ids):
             x0, y0, x1, y1 = self.rects[t]
             self.frame[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]

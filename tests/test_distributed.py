@@ -92,3 +92,21 @@ def test_hand_out_order():
     assert ft.order[0] == 5 and ft.order[-1] in (3, 11)  # the centre tile first, a far corner last
     ft._reorder([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11], [5, 1, 1, 9, 1, 1, 7, 1, 1, 1, 1, 1])
     assert ft.order[:3] == [3, 6, 0] and ft.order[3:] == [1, 2, 4, 5, 7, 8, 9, 10, 11]
+
+
+@pytest.mark.parametrize("shape", [(96, 72, 32, 24), (100, 72, 32, 24), (64, 64, 64, 64), (64, 48, 16, 48)])
+def test_tiles_land_where_their_rectangles_say(shape):
+    """_place puts a rank's tiles (any order) into the frame: whole-tile frames take one indexed copy, frames with
+    ragged edge tiles one copy per tile; both must equal the per-rectangle assignment (tile rows count from the
+    bottom of the frame, frame rows from the top)."""
+    import torch
+    W, H, tw, th = shape
+    ft = tiling.FrameTiler(W, H, tw, th, "cpu")
+    ids = list(np.random.default_rng(3).permutation(ft.n_tiles))
+    tiles = torch.rand(ft.n_tiles, th, tw, 3)
+    want = torch.zeros(H, W, 3)
+    for j, t in enumerate(ids):
+        x0, y0, x1, y1 = ft.rects[t]
+        want[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]
+    ft._place([int(t) for t in ids], tiles)
+    assert torch.equal(ft.frame, want)
