@@ -293,8 +293,8 @@ int srt_render(srt_device* dev, srt_scene* scene, const srt_render_params* param
  * holds on every GPU it is loaded on until the process ends; the call makes no hipMalloc / hipFree.
  * Limits, each refused with SRT_ERR_INVALID and a message: the output must be device memory (out->on_device = 1);
  * no SRT_F_TRANSPARENCY and no SRT_RENDER_TIMING; the rectangle must fit the array: about
- * sample_slots * (24 + shadow queries per hit; with SRT_F_RECURSIVE + 97 + 24 * max_depth) bytes, sample_slots = the rectangle padded to
- * whole 8 x 8-pixel blocks times samples per pixel (e.g. 256 x 256 pixels at 8 samples with 101 shadow queries).
+ * sample_slots * (40 + shadow queries per hit; with SRT_F_RECURSIVE + 97 + 24 * max_depth) bytes, sample_slots = the rectangle padded to
+ * whole 8 x 8-pixel blocks times samples per pixel (e.g. 240 x 240 pixels at 8 samples with 101 shadow queries).
  * Every call on a GPU uses that GPU's one array, whatever the handle or stream: calls that overlap on one GPU
  * race; serialize them (one stream, or events).  The array keeps the previous call's contents; the call clears
  * what it needs cleared. */

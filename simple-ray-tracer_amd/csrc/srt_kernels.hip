@@ -78,12 +78,13 @@ struct Stats {
     uint32_t wave_inner, wave_leaf; /* loop trips of the wave, tallied by its first active lane */
 };
 
-/* A queued path ray is three float4: (o.xyz, d.x) (d.y, d.z, thr.x, thr.y) (thr.z, sample, -, -). */
+/* A queued path ray is three float4: (o.xyz, d.x) (d.y, d.z, thr.x, thr.y) (thr.z, sample, sampler key, -). */
 
 struct HitQ {
     uint32_t* slot; /* primary: sample index; secondary: index into the path queue */
     float* t;
     uint32_t* tri; /* leaf-order triangle position */
+    float4* ip;    /* hit point o + d * t and, in w, the bits of the path's sampler key: all a shadow query needs of its hit */
 };
 
 struct RenderDev {
@@ -671,6 +672,9 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, Render
             hq.slot[q] = s;
             hq.t[q] = T;
             hq.tri[q] = tri;
+            const f3 ip = o + d * T;
+            const uint32_t path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
+            hq.ip[q] = make_float4(ip.x, ip.y, ip.z, __uint_as_float(path));
         }
     }
     flush_counters(cnt, nPath, 0, 0, st);
@@ -691,9 +695,10 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
         bool hit = false;
         float T = SRT_FLT_MAX;
         uint32_t tri = 0xFFFFFFFFu;
+        f3 o = mk3(0, 0, 0), d = mk3(0, 0, 1);
         if (i < n) {
             const float4 a = paths[3ull * i], b = paths[3ull * i + 1];
-            const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+            o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
             nPath += 1;
             hit = bvh_query<CULL, COUNT>(sc, features, o, d, T, tri, stk, st);
             if (!hit && (features & SRT_F_ENVIRONMENT)) {
@@ -717,6 +722,8 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
             hq.slot[q] = i;
             hq.t[q] = T;
             hq.tri[q] = tri;
+            const f3 ip = o + d * T;
+            hq.ip[q] = make_float4(ip.x, ip.y, ip.z, paths[3ull * i + 2].z); /* the sampler key travels with the ray */
         }
     }
     flush_counters(cnt, nPath, 0, 0, st);
@@ -750,21 +757,12 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
     path = ((uint32_t)py * (uint32_t)rp.cam.width + (uint32_t)px) * (uint32_t)rp.S + (uint32_t)sub;
 }
 
-/* Launch shape of the shadow kernel.  The kernel is bound by the rate at which a compute unit's vector memory path
- * takes per-lane 16-byte loads (measured with srt_probe_gather: about 1.4 per cycle and compute unit whichever cache
- * level answers; the walk sustains 1.07), so one option keeps the head of the node array in LDS next to the
- * stacks: with SRT_SHADOW_LDS_NODES > 0 the first that many records (top levels, if the host stored them breadth
- * first) are read with ds_read_b128 instead.  Measured on the 18-level stand-in (dragon frame's shadow launch,
- * 199.1 ms without): 768-thread blocks + 255 nodes (33 % of all node visits) 200.4 ms, 512 + 127 nodes 202.4 ms,
- * 1024 + 1023 nodes (44 % of visits, but 4 waves per SIMD) 225.5 ms: a wave's lanes are rarely all inside the
- * cached levels, so both fetch paths run in most steps and their waits add up, which costs what the saved loads
- * gain (the same kernel with the option compiled in but no node cached: 208.4 ms).  Hence off by default. */
+/* Launch shape of the shadow kernel.  (Keeping the head of the node array in LDS next to the stacks was measured and
+ * dropped: a wave's lanes are rarely all inside the cached levels, so both fetch paths run in most steps.) */
 #ifndef SRT_SHADOW_BLOCK
 #define SRT_SHADOW_BLOCK 256
 #endif
-#ifndef SRT_SHADOW_LDS_NODES
-#define SRT_SHADOW_LDS_NODES 0
-#endif
+#define SRT_LDS_LIGHTS 16u /* lights a block keeps in LDS; further ones are read from global memory */
 
 /* ---- shadow queries: a walk with four-byte stack entries.
  * Until a shadow query accepts its first hit, C is FLT_MAX: no pop test can skip a pending sibling, and the
@@ -869,20 +867,14 @@ SRT_DI bool swalk_pop(Walk& w, const uint32_t* stk)
 /* walk_inner with t = 1 and C = FLT_MAX: every value of a box in the fast ranges is finite, so the push test
  * `value < C` holds and a child is entered when its box passes (or always, without miss culling). */
 template <bool CULL, bool COUNT>
-SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st, const float4* lds_nodes, uint32_t n_lds)
+SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
 {
     if (COUNT) {
         st.inner += 1;
         st.box += 2;
     }
-    float4 a, b, c, e;
-    if (w.cur < n_lds) {
-        const float4* nd = lds_nodes + 4u * w.cur;
-        a = nd[0], b = nd[1], c = nd[2], e = nd[3];
-    } else {
-        const float4* nd = sc.nodes + 4ull * w.cur;
-        a = nd[0], b = nd[1], c = nd[2], e = nd[3];
-    }
+    const float4* nd = sc.nodes + 4ull * w.cur;
+    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
     const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
     const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
     const uint32_t left = __float_as_uint(e.x), right = __float_as_uint(e.y);
@@ -971,17 +963,17 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
 template <bool CULL, bool COUNT>
 __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
                                                               const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt,
-                                                              unsigned long long* next_chunk, uint32_t n_lds)
+                                                              unsigned long long* next_chunk)
 {
-    /* LDS: the first n_lds node records, then the per-lane stacks */
-    if (SRT_SHADOW_LDS_NODES == 0)
-        n_lds = 0; /* known at compile time: the LDS branch of the node fetch disappears */
-    extern __shared__ float4 lds_shadow[];
-    const float4* lds_nodes = lds_shadow;
-    for (uint32_t i = threadIdx.x; i < 4u * n_lds; i += SRT_SHADOW_BLOCK)
-        lds_shadow[i] = sc.nodes[i];
+    /* LDS: the first lights of the scene (a refill reads its light from here instead of global memory), then the
+     * per-lane stacks */
+    extern __shared__ uint32_t lds_shadow[];
+    const srt_light* lds_lights = (const srt_light*)lds_shadow;
+    const uint32_t nLdsLights = sc.n_lights < SRT_LDS_LIGHTS ? sc.n_lights : SRT_LDS_LIGHTS;
+    for (uint32_t i = threadIdx.x; i < nLdsLights * (uint32_t)(sizeof(srt_light) / 4); i += SRT_SHADOW_BLOCK)
+        lds_shadow[i] = ((const uint32_t*)sc.lights)[i];
     __syncthreads();
-    uint32_t* stk = (uint32_t*)(lds_shadow + 4u * n_lds) + threadIdx.x;
+    uint32_t* stk = lds_shadow + SRT_LDS_LIGHTS * (uint32_t)(sizeof(srt_light) / 4) + threadIdx.x;
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShadow = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1005,6 +997,15 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
         return first_shared + uniform(base); /* lane 0 is the first active lane: no lane leaves the loop before the wave does */
     };
     unsigned long long chunk = uniform((unsigned long long)blockIdx.x * SRT_SHADOW_BLOCK + (threadIdx.x & ~63u));
+    /* hit and sample number of a chunk's first item: one 64-bit division per chunk; the items of the chunk then
+     * need 32-bit arithmetic only */
+    uint32_t hitBase = 0, sampleBase = 0;
+    auto locate = [&](unsigned long long c) {
+        const unsigned long long q = c / shadows_per_hit;
+        hitBase = __builtin_amdgcn_readfirstlane((uint32_t)q);
+        sampleBase = __builtin_amdgcn_readfirstlane((uint32_t)(c - q * shadows_per_hit));
+    };
+    locate(chunk);
     bool dry = false;                                                                              /* the items have run out */
     uint32_t used = 0; /* items taken from the current chunk */
     Walk w;
@@ -1016,6 +1017,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
         const unsigned long long idle = __ballot(!busy);
         if (!dry && __popcll(idle) >= SRT_REFILL_MIN && used == 64u) {
             chunk = grab();
+            locate(chunk);
             used = 0;
         }
         dry = dry || chunk >= n;
@@ -1023,33 +1025,42 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             const uint32_t cnt = (uint32_t)__popcll(idle);
             const uint32_t pos = used + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
             unsigned long long mine = chunk + pos;
+            uint32_t hb = hitBase, within = sampleBase + pos;
             used += cnt;
             if (used > 64u) {
                 /* the idle lanes outnumber what is left of the chunk: the rest come from the next one */
                 chunk = grab();
+                locate(chunk);
                 used -= 64u;
-                if (pos >= 64u)
+                if (pos >= 64u) {
                     mine = chunk + (pos - 64u);
+                    hb = hitBase, within = sampleBase + (pos - 64u);
+                }
             }
             if (!busy && mine < n) {
                 item = mine;
-                const uint32_t h = (uint32_t)(item / shadows_per_hit);
-                uint32_t k = (uint32_t)(item - (unsigned long long)h * shadows_per_hit);
+                const uint32_t over = within / shadows_per_hit; /* hits between the chunk's first item and this one */
+                const uint32_t h = hb + over;
+                uint32_t k = within - over * shadows_per_hit;
+                const float4 hp = hq.ip[h]; /* hit point and sampler key, left by the trace kernel */
                 uint32_t li = 0;
                 for (; li < sc.n_lights; ++li) {
-                    const uint32_t c = shadow_samples(sc.lights[li].type, rp.features);
+                    const uint32_t type = li < nLdsLights ? lds_lights[li].type : sc.lights[li].type;
+                    const uint32_t c = shadow_samples(type, rp.features);
                     if (k < c)
                         break;
                     k -= c;
                 }
-                f3 o, d, thr;
-                float T;
-                uint32_t tri, sample, path;
-                hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
+                srt_light L;
+                if (li < nLdsLights)
+                    L = lds_lights[li];
+                else
+                    L = sc.lights[li];
+                const uint32_t path = __float_as_uint(hp.w);
                 f3 pos3, col;
-                light_sample(sc.lights + li, rp.seed, path, (uint32_t)depth, li, k, pos3, col);
+                light_sample(&L, rp.seed, path, (uint32_t)depth, li, k, pos3, col);
                 /* testVisibilityLightSample, reference src/light.cpp:54-62 */
-                const f3 ip = o + d * T;
+                const f3 ip = mk3(hp.x, hp.y, hp.z);
                 if (ip.x == pos3.x && ip.y == pos3.y && ip.z == pos3.z) {
                     vis[item] = 1;
                 } else {
@@ -1087,7 +1098,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
                 st.wave_inner += 1;
             if (atInner)
-                swalk_inner<CULL, COUNT>(sc, w, stk, st, lds_nodes, n_lds);
+                swalk_inner<CULL, COUNT>(sc, w, stk, st);
         } else {
             if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
                 st.wave_leaf += 1;
@@ -1126,12 +1137,13 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
         bool spawn = false, through = false;
         f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1), nthr = mk3(0, 0, 0);
         f3 to = mk3(0, 0, 0), td = mk3(0, 0, 1), tthr = mk3(0, 0, 0);
-        uint32_t sample = 0;
+        uint32_t sample = 0, pathKey = 0;
         if (h < n) {
             f3 o, d, thr;
             float T;
             uint32_t tri, path;
             hit_ray(rp, depth, hq, cur_paths, h, o, d, thr, T, tri, sample, path);
+            pathKey = path;
             Surface sf;
             surface_at(sc, rp.features, o, d, T, tri, sf);
             nShaded += 1;
@@ -1186,14 +1198,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
         if (spawn) {
             next_paths[3ull * q] = make_float4(ro.x, ro.y, ro.z, rd.x);
             next_paths[3ull * q + 1] = make_float4(rd.y, rd.z, nthr.x, nthr.y);
-            next_paths[3ull * q + 2] = make_float4(nthr.z, __uint_as_float(sample), 0.0f, 0.0f);
+            next_paths[3ull * q + 2] = make_float4(nthr.z, __uint_as_float(sample), __uint_as_float(pathKey), 0.0f);
         }
         if (rp.features & SRT_F_TRANSPARENCY) {
             const uint32_t q2 = queue_slot(through, next_count);
             if (through) {
                 next_paths[3ull * q2] = make_float4(to.x, to.y, to.z, td.x);
                 next_paths[3ull * q2 + 1] = make_float4(td.y, td.z, tthr.x, tthr.y);
-                next_paths[3ull * q2 + 2] = make_float4(tthr.z, __uint_as_float(sample), 0.0f, 0.0f);
+                next_paths[3ull * q2 + 2] = make_float4(tthr.z, __uint_as_float(sample), __uint_as_float(pathKey), 0.0f);
             }
         }
     }
@@ -1460,7 +1472,7 @@ struct srt_device {
     DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family, plus one for srt_intersect_batch */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
     unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
-    DevBuf acc, chain, nlev, hq_slot, hq_t, hq_tri, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
+    DevBuf acc, chain, nlev, hq_slot, hq_t, hq_tri, hq_ip, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
     hipEvent_t ev[SRT_MAX_EVENTS];
     int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
     int n_ev = 0;
@@ -1565,7 +1577,7 @@ void srt_device_destroy(srt_device* d)
         return;
     (void)hipSetDevice(d->gpu);
     (void)hipDeviceSynchronize();
-    DevBuf* bufs[] = { &d->acc, &d->chain, &d->nlev, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
+    DevBuf* bufs[] = { &d->acc, &d->chain, &d->nlev, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->hq_ip, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
         &d->out_t, &d->io_a, &d->io_b };
     for (DevBuf* b : bufs)
         b->release();
@@ -1807,8 +1819,7 @@ void srt_scene_destroy(srt_scene* s)
 /* Stack capacity: at most one pending left sibling per inner level. */
 static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + SRT_STACK_SLACK; }
 static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
-static uint32_t shadow_lds_nodes(const srt_scene* s) { return s->view.n_nodes < SRT_SHADOW_LDS_NODES ? s->view.n_nodes : SRT_SHADOW_LDS_NODES; }
-static size_t shadow_lds_bytes(const srt_scene* s) { return (size_t)shadow_lds_nodes(s) * 64 + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
+static size_t shadow_lds_bytes(const srt_scene* s) { return SRT_LDS_LIGHTS * sizeof(srt_light) + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
 
 template <typename K>
 static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid, int block = SRT_BLOCK)
@@ -1919,7 +1930,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         if (sph) {
             mark(d, st, 4, timing);
             hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
-                vis, sph, d->counters + 4, wk.chunk_counters + depth, shadow_lds_nodes(sc));
+                vis, sph, d->counters + 4, wk.chunk_counters + depth);
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
@@ -1943,11 +1954,12 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
             int rc = d->hq_slot.reserve((size_t)spawned * 4);
             if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)spawned * 4);
             if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)spawned * 4);
+            if (rc == SRT_OK) rc = d->hq_ip.reserve((size_t)spawned * 16);
             if (rc == SRT_OK) rc = d->vis.reserve((size_t)spawned * sph + 64);
             if (rc == SRT_OK) rc = d->path[depth & 1].reserve((size_t)spawned * 2 * 48);
             if (rc != SRT_OK)
                 return rc;
-            hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
+            hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p, (float4*)d->hq_ip.p };
             vis = (unsigned char*)d->vis.p;
             wk.path[depth & 1] = (float4*)d->path[depth & 1].p;
         }
@@ -2004,6 +2016,7 @@ static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t featur
     if (rc == SRT_OK) rc = d->hq_slot.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_t.reserve((size_t)n * 4);
     if (rc == SRT_OK) rc = d->hq_tri.reserve((size_t)n * 4);
+    if (rc == SRT_OK) rc = d->hq_ip.reserve((size_t)n * 16);
     /* one visibility byte per (hit, shadow sample); every sample of the rectangle may hit */
     if (rc == SRT_OK) rc = d->vis.reserve((size_t)n * sph + 64);
     if (rc == SRT_OK && (features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY))) {
@@ -2020,7 +2033,7 @@ static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t featur
         return rc;
     wk->acc = (float*)d->acc.p;
     wk->chain = (float*)d->chain.p, wk->nlev = (unsigned char*)d->nlev.p;
-    wk->hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p };
+    wk->hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p, (float4*)d->hq_ip.p };
     wk->vis = (unsigned char*)d->vis.p;
     wk->path[0] = (float4*)d->path[0].p, wk->path[1] = (float4*)d->path[1].p;
     wk->qcounts = d->qcounts;
@@ -2165,6 +2178,7 @@ int srt_render_noalloc(srt_device* d, srt_scene* sc, const srt_render_params* p,
     wk.hq.slot = (uint32_t*)carve((size_t)n * 4);
     wk.hq.t = (float*)carve((size_t)n * 4);
     wk.hq.tri = (uint32_t*)carve((size_t)n * 4);
+    wk.hq.ip = (float4*)carve((size_t)n * 16);
     wk.vis = carve((size_t)n * sph + 64);
     if (paths) {
         wk.path[0] = (float4*)carve((size_t)n * 48);

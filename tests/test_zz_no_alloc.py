@@ -59,14 +59,14 @@ def test_noalloc_refusals():
     srt.set_device(0)
     bvh = srt.Bvh(srt.Scene.from_arrays(_scene("monkey")), srt.F_ACCEL)
     feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_RECURSIVE | srt.F_MISS_CULL
-    W, H = 2048, 2048  # 4 Mi samples x 121 bytes: beyond the 64 MiB area
+    W, H = 2048, 2048  # 4 Mi samples x 258 bytes: beyond the 64 MiB area
     buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     cam = srt.make_camera(W, H)
     stream = torch.cuda.current_stream().cuda_stream
     with pytest.raises(srt.SrtError, match="scratch area"):
         bvh.render_device_noalloc(bvh.params(cam, feat, 1, 1, 5, 0, None, 0), buf.data_ptr(), W, H, 0, 0, stream)
     # the same frame in rectangles that fit is fine and equals srt_render
-    part = (512, 512, 1024, 1024)
+    part = (512, 512, 960, 960)
     bvh.render_device_noalloc(bvh.params(cam, feat, 1, 1, 5, 0, part, 0), buf.data_ptr(), W, H, 0, 0, stream)
     ref = torch.zeros_like(buf)
     bvh.render_device(bvh.params(cam, feat, 1, 1, 5, 0, part, 0), ref.data_ptr(), W, H, 0, 0, stream)
