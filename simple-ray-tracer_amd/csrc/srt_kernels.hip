@@ -918,10 +918,10 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
         const float4* r0 = sc.tris + 6ull * (first + k);
         const bool two = k + 1 < cnt;
         const float4* r1 = two ? r0 + 6 : r0;
-        const float4 a0 = r0[0], a1 = r1[0];
         if (COUNT)
             st.tri += two ? 2 : 1;
         float nt0, nt1;
+        const float4 a0 = r0[0], a1 = r1[0];
         const bool c0 = tri_plane(a0, w.o, w.d, nt0) && nt0 <= T;
         const bool c1 = two && tri_plane(a1, w.o, w.d, nt1) && nt1 <= T;
         bool in0 = false, in1 = false;
