@@ -321,6 +321,22 @@ def test_mixed_lights(orc, pair):
     _compare_frames(got, want, "three light types")
 
 
+def test_many_lights(orc, pair):
+    """More lights than a block of the shadow kernel keeps in LDS (16): the later ones are read from global memory.
+    18 point lights and, last, a segment light: 18 + 100 shadow queries per hit (a chunk of 64 queries spans hits), and
+    with hard shadows only 18 per hit (several hits per chunk)."""
+    rng = np.random.default_rng(4)
+    lights = [orc.point_light((float(x), 0.55, float(z)), (0.08, 0.08, 0.08)) for x, z in rng.uniform(-0.4, 0.4, (18, 2))]
+    lights.append(orc.segment_light((0.25, 0.5, 0.1), (-0.25, 0.5, -0.1), (0.3, 0, 0), (0, 0, 0.3)))
+    ob, gb = pair("cornell", lights)
+    for feat, what in ((SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MISS_CULL, "19 lights"),
+                       (SH | srt.F_HARD_SHADOW | srt.F_RECURSIVE | srt.F_MISS_CULL, "19 lights, hard shadows only")):
+        want = ob.render(orc.make_camera(40, 40), feat, seed=3)
+        got = gb.render(srt.make_camera(40, 40), feat, seed=3)
+        _compare_frames(got, want, what)
+        assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
+
+
 @pytest.mark.parametrize("policy", ["reference", "cull"])
 @pytest.mark.parametrize("name,behind", [("cornell", 0.004), ("monkey", 0.0005)])
 def test_shadow_hit_just_before_light(orc, pair, name, behind, policy):
