@@ -398,6 +398,10 @@ def main():
                          "concurrent_lanes": len(lanes),  # > 1: launches of different tiles overlap, so do their timed intervals
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times},
+                         # the same achieved / peak ratio for every traversal family (per frame: bytes over summed launch time)
+                         "by_kernel": {n: {"achieved": algorithmic_bytes(fam[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9,
+                                           "frac": algorithmic_bytes(fam[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9 / l2_peak}
+                                       for n in times if n.startswith("trace_") and times[n]["ms"] > 0 and l2_peak > 0},
                          "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]}},
         }
         if world == 1:
