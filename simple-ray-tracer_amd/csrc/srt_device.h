@@ -200,7 +200,7 @@ SRT_DI bool tri_plane(const float4 q0, f3 o, f3 d, float& nt)
 /* pointInTriangle for p = o + d * nt (reference src/intersect.cpp:13-26) on the record's three vertex quarters, for
  * the shadow walk.  The second operands of the three sameSide tests are ray independent and the record stores them
  * (tri_test reads them), but here they are recomputed from the vertices, with the operations that made the stored
- * ones: 30 more vector instructions per test against two fewer 16-byte loads per lane, and it is load instructions
+ * ones: 30 more vector instructions per test against two fewer 16-byte loads per lane, and it is per-lane loads
  * the shadow kernel runs out of (measured: shadow launch of the dragon frame 192.4 -> 183.6 ms; the closest-hit
  * kernels, which are not, lose 2 % that way and keep the loads). */
 SRT_DI bool tri_inside(const float4* __restrict__ rec, f3 o, f3 d, float nt)
