@@ -49,12 +49,12 @@ struct Huffman {
             firstCode[len] = code;
             firstIndex[len] = index;
             for (int k = 0; k < counts[len - 1]; ++k, ++code, ++index) {
+                if (code >= (1 << len))
+                    return false; /* more codes than the length can hold */
                 if (len <= 9)
                     for (int f = 0; f < (1 << (9 - len)); ++f)
                         fast[(code << (9 - len)) | f] = (int16_t)((len << 8) | values[index]);
             }
-            if (code > (1 << len))
-                return false; /* more codes than the length can hold */
             maxCode[len] = counts[len - 1] ? code - 1 : -1;
             code <<= 1;
         }
@@ -85,7 +85,7 @@ struct BitReader {
                         c = byteAt(pos++);
                     if (c != 0) {
                         marker = c;
-                        return;
+                        b = 0; /* zeros from here on, so that the bit count never falls below what a caller drops */
                     }
                 }
             }
@@ -330,6 +330,10 @@ struct Decoder {
             return false;
         height = get16(), width = get16();
         if (height == 0 || width == 0)
+            return false;
+        /* every 8 x 8 block costs the entropy-coded data at least two bits, so a frame far larger than its file can
+         * hold is refused before its planes are allocated */
+        if ((uint64_t)width * height > 1024ull * size + 65536ull)
             return false;
         nComp = get8();
         if ((nComp != 1 && nComp != 3 && nComp != 4) || Lf != 8 + 3 * nComp)

@@ -702,6 +702,10 @@ bool decodePng(const std::vector<uint8_t>& file, int& w, int& h, std::vector<uin
         if (w > ps.x0 && h > ps.y0 && pw && ph)
             rawSize += ((pw * bitsPerPixel + 7) / 8 + 1) * ph;
     }
+    /* deflate expands by at most 1032 : 1, so a header that promises more than the data can hold is refused
+     * before anything of that size is allocated (the length check after uncompress would refuse it anyway) */
+    if (w > (1 << 24) || h > (1 << 24) || rawSize > idat.size() * 1032 + 1024)
+        return false;
     std::vector<uint8_t> raw(rawSize);
     uLongf rawLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
@@ -806,6 +810,21 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
     if (!loadObj(obj, file.string(), baseDir.string())) {
         std::cerr << "Failed to load mesh " << file << std::endl;
         throw LoadError();
+    }
+    /* Indices that point outside the file's arrays are undefined behaviour in the reference's loader; here the file
+     * is refused. */
+    const long nV = (long)(obj.v.size() / 3), nVn = (long)(obj.vn.size() / 3), nVt = (long)(obj.vt.size() / 2), nMat = (long)obj.materials.size();
+    for (const Shape& shape : obj.shapes) {
+        for (const Idx& ix : shape.indices)
+            if (ix.v < 0 || ix.v >= nV || ix.vn < -1 || (nVn && ix.vn >= nVn) || ix.vt < -1 || (nVt && ix.vt >= nVt)) { /* an empty normal / uv array is never indexed */
+                std::cerr << "Mesh " << file << " refers to a vertex, normal or texture coordinate it does not define" << std::endl;
+                throw LoadError();
+            }
+        for (int id : shape.materialIds)
+            if (id < -1 || id >= nMat) {
+                std::cerr << "Mesh " << file << " refers to a material it does not define" << std::endl;
+                throw LoadError();
+            }
     }
     auto pos = [&](int vi) { return vec3(obj.v[3 * (size_t)vi], obj.v[3 * (size_t)vi + 1], obj.v[3 * (size_t)vi + 2]); };
     std::vector<Mesh> out;

@@ -225,6 +225,31 @@ def test_image_loader_refuses_what_it_cannot_decode(tmp_path):
             srt.load_image(str(p))
 
 
+def test_readers_refuse_files_that_point_outside_themselves(tmp_path):
+    """Inputs the reference's libraries answer with undefined behaviour (found by tools/fuzz): a Huffman table with
+    more codes than its code length can hold, an image header that promises far more pixels than the file can encode,
+    face indices beyond the vertex list.  Here they are refused."""
+    good = bytearray(open(os.path.join(GOLD, "image_cases", "base444.jpg"), "rb").read())
+    at = good.index(b"\xff\xc4")
+    bad_table = bytearray(good)
+    bad_table[at + 5] = 255  # 255 codes of length 1
+    huge = bytearray(good)
+    sof = huge.index(b"\xff\xc0")
+    huge[sof + 5:sof + 9] = b"\xff\xff\xff\xff"  # 65535 x 65535
+    png = bytearray(open(os.path.join(GOLD, "image_cases", "ilace_rgb.png"), "rb").read())
+    png[16:24] = b"\x00\xff\xff\xff\x00\xff\xff\xff"  # IHDR width and height (the CRC is not checked, as in stb_image)
+    for name, data in {"bad_table.jpg": bad_table, "huge.jpg": huge, "huge.png": png}.items():
+        p = tmp_path / name
+        p.write_bytes(bytes(data))
+        with pytest.raises(srt.SrtError):
+            srt.load_image(str(p))
+    for k, face in enumerate(("f 1 2 9", "f -1 -2 -7", "f 1/5 2/1 3/1", "f 1//4 2//1 3//1")):
+        p = tmp_path / f"bad{k}.obj"
+        p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + face + "\n")
+        with pytest.raises(srt.SrtError):
+            srt.Scene.from_obj(str(p))
+
+
 def test_missing_file_raises():
     with pytest.raises(srt.SrtError):
         srt.Scene.from_obj("/nonexistent/x.obj")
