@@ -254,7 +254,7 @@ class Bvh:
         self.h = lib().orc_bvh_build(C.byref(self.scene.struct), features)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:  # at interpreter shutdown the module's globals may be gone
             lib().orc_bvh_free(self.h)
             self.h = None
 

@@ -1150,7 +1150,9 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             const f3 Lo = light_contribution(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, vis, (unsigned long long)h * shadows_per_hit);
             /* Share of this hit's own light in the sample.  With transparency (reference src/render.cpp:111-120) a
              * hit at the depth cap, or of a material with transparency above 1, returns black; a material with
-             * transparency tr < 1 keeps tr of its light (and of its reflection) and passes 1 - tr on. */
+             * transparency tr < 1 keeps tr of its light (and of its reflection) and passes 1 - tr on.  A hit that
+             * returns black sends on no ray at all; the reference still follows its reflection and discards the result,
+             * so the pixels are the same and the ray count is smaller. */
             const bool seeThrough = (rp.features & SRT_F_TRANSPARENCY) != 0;
             const float tr = sf.transparency;
             const bool black = seeThrough && !(depth < rp.max_depth && tr <= 1.0f);
