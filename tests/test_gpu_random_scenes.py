@@ -7,9 +7,16 @@ import sys
 import pytest
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
 def test_random_scenes_match_the_oracle(orc):
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import diff_fuzz
     assert diff_fuzz.run(10000, 180) == 0
+
+
+def test_random_soups_build_like_the_host_builder():
+    """Random triangle soups (ties, sorted, reversed, clustered, all-equal keys; 1 to 60 000 triangles): the device-side
+    build gives the host builder's arrays bit for bit."""
+    import build_fuzz
+    assert build_fuzz.run(5000, 120) == 0
