@@ -128,7 +128,7 @@ class FrameTiler:
         """Finished tiles of every rank into rank 0's frame (Screen layout: top row first)."""
         t0 = time.perf_counter()
         self._measure(k)  # also waits for this rank's tiles, whatever streams they were rendered on
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             if self.n_tiles == 1 and (self.tw, self.th) == (self.W, self.H):
                 self.frame.copy_(self.tiles[0])  # one tile: rendered on the current stream, which orders the copy
             else:
@@ -157,7 +157,8 @@ class FrameTiler:
         self._reorder(owners, costs)
         if self.rank == 0:
             # arm the counter two frames ahead: no rank can be past frame step + 1 before the next gather
-            self.counter.reset(self.step + 2)
+            if self.counter is not None:
+                self.counter.reset(self.step + 2)
             bufs = {r: torch.empty((counts[r], self.th, self.tw, 3), dtype=torch.float32, device=self.device)
                     for r in range(1, self.world) if counts[r]}
             # one batch: the receives from all peers run side by side, each over its own link

@@ -1,0 +1,53 @@
+"""The tile gather over RCCL on the one GPU a test box has: a process group of one rank (RCCL refuses two ranks on one
+device), so the group set-up bound to the device, the all_gather of tile ids on device tensors, the barrier and the
+placement run through RCCL; only the peer-to-peer transfer has no peer.  Runs in a child process, so that the test
+process itself never holds a process group."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import importlib, os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "oracle"))
+import orc
+srt = importlib.import_module("simple-ray-tracer_amd")
+tiling = importlib.import_module("simple-ray-tracer_amd.distributed")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[2], RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+srt.set_device(0)
+d = orc.load_scene_npz(os.path.join(sys.argv[1], "tests", "golden", "scenes", "cornell.npz"))
+bvh = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+W, H, tw, th = 96, 64, 32, 16
+cam = srt.make_camera(W, H)
+feats = srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_ACCEL | srt.F_MISS_CULL
+whole = bvh.render(cam, feats, 1, 1, 0, primary=False)["rgb"]
+tiler = tiling.FrameTiler(W, H, tw, th, dev, 0, 1, None)
+def render_tile(rect, slot):
+    p = bvh.params(cam, feats, 1, 1, 0, 0, rect, 0)
+    bvh.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], torch.cuda.current_stream().cuda_stream)
+for _ in range(2):  # the second frame goes out in the order the first frame's tile times give
+    k = tiler.render(render_tile, None)
+    tiler.gather(k)
+    dist.barrier()
+    torch.cuda.synchronize()
+    assert k == tiler.n_tiles == 12
+    assert np.array_equal(tiler.frame.cpu().numpy(), whole)
+dist.destroy_process_group()
+print("rccl gather ok")
+"""
+
+
+@pytest.mark.gpu
+def test_tile_gather_over_rccl_with_one_rank(tmp_path):
+    script = tmp_path / "child.py"
+    script.write_text(CHILD)
+    r = subprocess.run([sys.executable, "-u", str(script), ROOT, "29541"], capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "rccl gather ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
