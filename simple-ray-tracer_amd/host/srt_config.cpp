@@ -18,91 +18,139 @@ std::filesystem::path defaultDataDir()
     return std::filesystem::current_path() / "data";
 }
 
-static const char* sceneTypeName(SceneType t)
-{
-    switch (t) {
-    case SingleTriangle: return "SceneType::SingleTriangle";
-    case Cube: return "SceneType::Cube";
-    case CubeTextured: return "SceneType::CubeTextured";
-    case CornellBox: return "SceneType::CornellBox";
-    case CornellBoxParallelogramLight: return "SceneType::CornellBoxParallelogramLight";
-    case Monkey: return "SceneType::Monkey";
-    case Teapot: return "SceneType::Teapot";
-    case Dragon: return "SceneType::Dragon";
-    case Spheres: return "SceneType::Spheres";
-    case Custom: return "SceneType::Custom";
-    }
-    return "SceneType::?";
-}
+/* The prebuilt scenes: enumerator name as the reference's printer writes it, and the key of a configuration file.  The
+ * reader takes the key as written, with hyphens for the underscores, or with the underscores left out, in any letter case
+ * (reference src/config.cpp:404-431); the writer emits the key (reference src/config.cpp:376-402). */
+static const struct SceneName {
+    SceneType type;
+    const char* enumerator;
+    const char* key;
+} kSceneNames[] = {
+    { SingleTriangle, "SingleTriangle", "single_triangle" },
+    { Cube, "Cube", "cube" },
+    { CubeTextured, "CubeTextured", "cube_textured" },
+    { CornellBox, "CornellBox", "cornell_box" },
+    { CornellBoxParallelogramLight, "CornellBoxParallelogramLight", "cornell_box_parallelogram_light" },
+    { Monkey, "Monkey", "monkey" },
+    { Teapot, "Teapot", "teapot" },
+    { Dragon, "Dragon", "dragon" },
+    { Spheres, "Spheres", "spheres" },
+    { Custom, "Custom", "custom" },
+};
 
-static std::ostream& operator<<(std::ostream& os, const vec3& v) { return os << "[" << v.x << ", " << v.y << ", " << v.z << "]"; }
+/* The feature switches of a configuration file, in the order the report lists them.  `required`: the reader insists on
+ * the key (the reference dereferences it unchecked); `read`: false for switches the reference's reader never looks at
+ * although its report prints them. */
+struct Switch {
+    const char* key;
+    bool Features::*core;
+    bool ExtraFeatures::*extra;
+    bool read;
+};
+static const Switch kCoreSwitches[] = {
+    { "enable_shading", &Features::enableShading, nullptr, true },
+    { "enable_recursive", &Features::enableRecursive, nullptr, true },
+    { "enable_hard_shadow", &Features::enableHardShadow, nullptr, true },
+    { "enable_soft_shadow", &Features::enableSoftShadow, nullptr, false },
+    { "enable_normal_interp", &Features::enableNormalInterp, nullptr, true },
+    { "enable_texture_mapping", &Features::enableTextureMapping, nullptr, true },
+    { "enable_accel_structure", &Features::enableAccelStructure, nullptr, true },
+};
+static const Switch kExtraSwitches[] = {
+    { "enable_bloom_effect", nullptr, &ExtraFeatures::enableBloomEffect, true },
+    { "enable_multiple_rays_per_pixel", nullptr, &ExtraFeatures::enableMultipleRaysPerPixel, true },
+    { "enable_motion_blur", nullptr, &ExtraFeatures::enableMotionBlur, true },
+    { "enable_depth_of_field", nullptr, &ExtraFeatures::enableDepthOfField, true },
+    { "enable_glossy_reflection", nullptr, &ExtraFeatures::enableGlossyReflection, true },
+    { "enable_transparency", nullptr, &ExtraFeatures::enableTransparency, false },
+    { "enable_bvh_sah_binning", nullptr, &ExtraFeatures::enableBvhSahBinning, false },
+    { "enable_environment_mapping", nullptr, &ExtraFeatures::enableEnvironmentMapping, true },
+    { "enable_bilinear_texture_filtering", nullptr, &ExtraFeatures::enableBilinearTextureFiltering, true },
+    { "enable_mipmap_texture_filtering", nullptr, &ExtraFeatures::enableMipmapTextureFiltering, true },
+};
 
-/* Layout of the reference's printer (src/config.cpp:71-148), followed by the back-end keys. */
+namespace {
+/* The report is an indented list: "  + " opens a group, "    - " an entry, six blanks continue an entry. */
+struct Report {
+    std::ostream& os;
+    template <class T> void line(const char* lead, const char* name, const T& value) { os << lead << name << ": " << value << std::endl; }
+    void group(const char* name) { os << "  + " << name << ": " << std::endl; }
+    template <class T> void top(const char* name, const T& value) { line("  + ", name, value); }
+    template <class T> void entry(const char* name, const T& value) { line("    - ", name, value); }
+    template <class T> void more(const char* name, const T& value) { line("      ", name, value); }
+};
+struct Bracketed {
+    const vec3& v;
+};
+std::ostream& operator<<(std::ostream& os, const Bracketed& b) { return os << "[" << b.v.x << ", " << b.v.y << ", " << b.v.z << "]"; }
+/* two bracketed vectors on one line: "a: [..], b: [..]" after the first name */
+struct Pair {
+    const vec3& first;
+    const char* secondName;
+    const vec3& second;
+};
+std::ostream& operator<<(std::ostream& os, const Pair& p) { return os << Bracketed { p.first } << ", " << p.secondName << ": " << Bracketed { p.second }; }
+} // namespace
+
+/* Prints what the reference's report prints, line for line (reference src/config.cpp:71-145: tools that read its
+ * console output keep working), then the keys of the [mi355x] table. */
 std::ostream& operator<<(std::ostream& os, const Config& config)
 {
-    const Features& f = config.features;
-    os << "Final Project Configurations: " << std::endl
-       << std::boolalpha << "  + command_line_rendering: " << config.cliRenderingEnabled << std::endl
-       << "  + window_size: " << config.windowSize.x << ", " << config.windowSize.y << std::endl
-       << "  + data_path: " << config.dataPath << std::endl
-       << "  + scene: ";
-    if (std::holds_alternative<SceneType>(config.scene))
-        os << sceneTypeName(std::get<SceneType>(config.scene)) << std::endl;
-    else
-        os << std::get<std::filesystem::path>(config.scene) << std::endl;
-    os << "  + output_filepath: " << config.outputDir << std::endl
-       << "  + features: " << std::endl
-       << "    - enable_shading: " << f.enableShading << std::endl
-       << "    - enable_recursive: " << f.enableRecursive << std::endl
-       << "    - enable_hard_shadow: " << f.enableHardShadow << std::endl
-       << "    - enable_soft_shadow: " << f.enableSoftShadow << std::endl
-       << "    - enable_normal_interp: " << f.enableNormalInterp << std::endl
-       << "    - enable_texture_mapping: " << f.enableTextureMapping << std::endl
-       << "    - enable_accel_structure: " << f.enableAccelStructure << std::endl
-       << "  + extra_features: " << std::endl
-       << "    - enable_bloom_effect: " << f.extra.enableBloomEffect << std::endl
-       << "    - enable_multiple_rays_per_pixel: " << f.extra.enableMultipleRaysPerPixel << std::endl
-       << "    - enable_motion_blur: " << f.extra.enableMotionBlur << std::endl
-       << "    - enable_depth_of_field: " << f.extra.enableDepthOfField << std::endl
-       << "    - enable_glossy_reflection: " << f.extra.enableGlossyReflection << std::endl
-       << "    - enable_transparency: " << f.extra.enableTransparency << std::endl
-       << "    - enable_bvh_sah_binning: " << f.extra.enableBvhSahBinning << std::endl
-       << "    - enable_environment_mapping: " << f.extra.enableEnvironmentMapping << std::endl
-       << "    - enable_bilinear_texture_filtering: " << f.extra.enableBilinearTextureFiltering << std::endl
-       << "    - enable_mipmap_texture_filtering: " << f.extra.enableMipmapTextureFiltering << std::endl;
-    os << "  + cameras: " << std::endl;
-    for (const CameraConfig& camera : config.cameras)
-        os << "    - field_of_view: " << camera.fieldOfView << std::endl
-           << "      distance_from_look_at: " << camera.distanceFromLookAt << std::endl
-           << "      look_at: " << camera.lookAt << std::endl
-           << "      rotation: " << camera.rotation << std::endl;
-    os << "  + lights: " << std::endl;
-    for (const Light& elem : config.lights) {
-        if (const auto* p = std::get_if<PointLight>(&elem)) {
-            os << "    - type: point" << std::endl << "      position: " << p->position << ", color: " << p->color << std::endl;
-        } else if (const auto* s = std::get_if<SegmentLight>(&elem)) {
-            os << "    - type: segment" << std::endl
-               << "      endpoint0: " << s->endpoint0 << ", endpoint1: " << s->endpoint1 << std::endl
-               << "      color0: " << s->color0 << ", color1: " << s->color1 << std::endl;
-        } else if (const auto* q = std::get_if<ParallelogramLight>(&elem)) {
-            os << "    - type: parallelogram" << std::endl
-               << "      v0: " << q->v0 << std::endl
-               << "      edge01: " << q->edge01 << ", edge02: " << q->edge02 << std::endl
-               << "      color0: " << q->color0 << ", color1: " << q->color1 << std::endl
-               << "      color2: " << q->color2 << ", color3: " << q->color3 << std::endl;
+    Report r { os };
+    os << "Final Project Configurations: " << std::endl << std::boolalpha;
+    r.top("command_line_rendering", config.cliRenderingEnabled);
+    os << "  + window_size: " << config.windowSize.x << ", " << config.windowSize.y << std::endl;
+    r.top("data_path", config.dataPath);
+    if (const SceneType* type = std::get_if<SceneType>(&config.scene)) {
+        std::string name = "SceneType::?";
+        for (const SceneName& n : kSceneNames)
+            if (n.type == *type)
+                name = std::string("SceneType::") + n.enumerator;
+        r.top("scene", name);
+    } else {
+        r.top("scene", std::get<std::filesystem::path>(config.scene));
+    }
+    r.top("output_filepath", config.outputDir);
+    r.group("features");
+    for (const Switch& sw : kCoreSwitches)
+        r.entry(sw.key, config.features.*sw.core);
+    r.group("extra_features");
+    for (const Switch& sw : kExtraSwitches)
+        r.entry(sw.key, config.features.extra.*sw.extra);
+    r.group("cameras");
+    for (const CameraConfig& camera : config.cameras) {
+        r.entry("field_of_view", camera.fieldOfView);
+        r.more("distance_from_look_at", camera.distanceFromLookAt);
+        r.more("look_at", Bracketed { camera.lookAt });
+        r.more("rotation", Bracketed { camera.rotation });
+    }
+    r.group("lights");
+    for (const Light& light : config.lights) {
+        if (const auto* p = std::get_if<PointLight>(&light)) {
+            r.entry("type", "point");
+            r.more("position", Pair { p->position, "color", p->color });
+        } else if (const auto* s = std::get_if<SegmentLight>(&light)) {
+            r.entry("type", "segment");
+            r.more("endpoint0", Pair { s->endpoint0, "endpoint1", s->endpoint1 });
+            r.more("color0", Pair { s->color0, "color1", s->color1 });
+        } else if (const auto* q = std::get_if<ParallelogramLight>(&light)) {
+            r.entry("type", "parallelogram");
+            r.more("v0", Bracketed { q->v0 });
+            r.more("edge01", Pair { q->edge01, "edge02", q->edge02 });
+            r.more("color0", Pair { q->color0, "color1", q->color1 });
+            r.more("color2", Pair { q->color2, "color3", q->color3 });
         }
     }
     const BackendConfig& b = config.backend;
-    os << "  + mi355x: " << std::endl
-       << "    - gpu: " << b.gpu << std::endl
-       << "    - num_rays: " << b.numRays << std::endl
-       << "    - enable_soft_shadow: " << b.enableSoftShadow << std::endl
-       << "    - enable_transparency: " << b.enableTransparency << std::endl
-       << "    - traversal: " << (b.referenceTraversal ? "reference" : "miss-cull") << std::endl
-       << "    - max_depth: " << b.maxDepth << std::endl
-       << "    - seed: " << b.seed << std::endl
-       << "    - motion blur: samples " << b.mbSamples << ", time0 " << b.time0 << ", time1 " << b.time1 << ", direction [" << b.direction.x << ", "
-       << b.direction.y << ", " << b.direction.z << "]" << std::endl
+    r.group("mi355x");
+    r.entry("gpu", b.gpu);
+    r.entry("num_rays", b.numRays);
+    r.entry("enable_soft_shadow", b.enableSoftShadow);
+    r.entry("enable_transparency", b.enableTransparency);
+    r.entry("traversal", b.referenceTraversal ? "reference" : "miss-cull");
+    r.entry("max_depth", b.maxDepth);
+    r.entry("seed", b.seed);
+    os << "    - motion blur: samples " << b.mbSamples << ", time0 " << b.time0 << ", time1 " << b.time1 << ", direction " << Bracketed { b.direction } << std::endl
        << "    - depth of field: samples " << b.dofSamples << ", focal_length " << b.focalLength << ", aperture " << b.aperture << std::endl;
     return os;
 }
@@ -219,21 +267,13 @@ static Config fromTable(const toml::Value& table)
     }
 
     const toml::Value& features = table["features"];
-    config.features.enableShading = mandatoryBool(features["enable_shading"], "features.enable_shading");
-    config.features.enableRecursive = mandatoryBool(features["enable_recursive"], "features.enable_recursive");
-    config.features.enableHardShadow = mandatoryBool(features["enable_hard_shadow"], "features.enable_hard_shadow");
-    config.features.enableNormalInterp = mandatoryBool(features["enable_normal_interp"], "features.enable_normal_interp");
-    config.features.enableTextureMapping = mandatoryBool(features["enable_texture_mapping"], "features.enable_texture_mapping");
-    config.features.enableAccelStructure = mandatoryBool(features["enable_accel_structure"], "features.enable_accel_structure");
+    for (const Switch& sw : kCoreSwitches)
+        if (sw.read)
+            config.features.*sw.core = mandatoryBool(features[sw.key], (std::string("features.") + sw.key).c_str());
     const toml::Value& extra = features["extra"];
-    optionalBool(extra["enable_bloom_effect"], config.features.extra.enableBloomEffect);
-    optionalBool(extra["enable_multiple_rays_per_pixel"], config.features.extra.enableMultipleRaysPerPixel);
-    optionalBool(extra["enable_motion_blur"], config.features.extra.enableMotionBlur);
-    optionalBool(extra["enable_depth_of_field"], config.features.extra.enableDepthOfField);
-    optionalBool(extra["enable_glossy_reflection"], config.features.extra.enableGlossyReflection);
-    optionalBool(extra["enable_environment_mapping"], config.features.extra.enableEnvironmentMapping);
-    optionalBool(extra["enable_bilinear_texture_filtering"], config.features.extra.enableBilinearTextureFiltering);
-    optionalBool(extra["enable_mipmap_texture_filtering"], config.features.extra.enableMipmapTextureFiltering);
+    for (const Switch& sw : kExtraSwitches)
+        if (sw.read)
+            optionalBool(extra[sw.key], config.features.extra.*sw.extra);
 
     const toml::Value& cameras = table["cameras"];
     for (size_t k = 0; k < cameras.size(); ++k) {
@@ -307,35 +347,27 @@ Config readConfigFile(const std::filesystem::path& configPath)
 
 std::string serialize(const SceneType& sceneType)
 {
-    switch (sceneType) {
-    case SingleTriangle: return "single_triangle";
-    case Cube: return "cube";
-    case CubeTextured: return "cube_textured";
-    case CornellBox: return "cornell_box";
-    case CornellBoxParallelogramLight: return "cornell_box_parallelogram_light";
-    case Monkey: return "monkey";
-    case Teapot: return "teapot";
-    case Dragon: return "dragon";
-    case Spheres: return "spheres";
-    case Custom: return "custom";
-    default: return "unknown";
-    }
+    for (const SceneName& n : kSceneNames)
+        if (n.type == sceneType)
+            return n.key;
+    return "unknown";
 }
 
 std::optional<SceneType> deserialize(const std::string& sceneTypeStr)
 {
-    std::string s;
-    std::transform(sceneTypeStr.begin(), sceneTypeStr.end(), std::back_inserter(s), [](unsigned char c) { return (char)std::tolower(c); });
-    if (s == "single_triangle" || s == "singletriangle" || s == "single-triangle") return SingleTriangle;
-    if (s == "cube") return Cube;
-    if (s == "cube-textured" || s == "cube_textured" || s == "cubetextured") return CubeTextured;
-    if (s == "cornell_box" || s == "cornellbox" || s == "cornell-box") return CornellBox;
-    if (s == "cornell_box_parallelogram_light" || s == "cornellboxparallelogramlight" || s == "cornell-box-parallelogram-light") return CornellBoxParallelogramLight;
-    if (s == "monkey") return Monkey;
-    if (s == "teapot") return Teapot;
-    if (s == "dragon") return Dragon;
-    if (s == "spheres") return Spheres;
-    if (s == "custom") return Custom;
+    std::string wanted;
+    for (unsigned char c : sceneTypeStr)
+        wanted.push_back((char)std::tolower(c));
+    for (const SceneName& n : kSceneNames) {
+        std::string hyphens, joined;
+        for (const char* c = n.key; *c; ++c) {
+            hyphens.push_back(*c == '_' ? '-' : *c);
+            if (*c != '_')
+                joined.push_back(*c);
+        }
+        if (wanted == n.key || wanted == hyphens || wanted == joined)
+            return n.type;
+    }
     return std::nullopt;
 }
 

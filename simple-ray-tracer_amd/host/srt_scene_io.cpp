@@ -799,6 +799,69 @@ Image::Image(const std::filesystem::path& filePath)
 
 std::shared_ptr<Image> loadEnvironment(const std::filesystem::path& dataDir) { return std::make_shared<Image>(dataDir / "cube_map.jpg"); }
 
+/* Triangle ranges [first, last) of a shape's sub-meshes: one per run of equal material ids, where a boundary is only
+ * looked for at triangles 1 .. n-2 - a last triangle with a material of its own stays in the run before it, as in the
+ * reference's splitting loop (reference framework/src/mesh.cpp:76-85, 141). */
+static std::vector<std::pair<size_t, size_t>> materialRuns(const std::vector<int>& ids, size_t n)
+{
+    std::vector<std::pair<size_t, size_t>> runs;
+    if (n == 0)
+        return runs;
+    size_t first = 0;
+    for (size_t t = 1; t + 1 < n; ++t)
+        if (ids[t] != ids[t - 1]) {
+            runs.emplace_back(first, t);
+            first = t;
+        }
+    runs.emplace_back(first, n);
+    return runs;
+}
+
+/* One sub-mesh: corners become vertices in first-seen order, a corner equal to an earlier one in position, normal and
+ * texture coordinate shares its vertex; corners without a normal in the file take the triangle's geometric normal
+ * (reference framework/src/mesh.cpp:87-137). */
+static Mesh subMesh(const ObjFile& obj, const Shape& shape, size_t first, size_t last, const std::filesystem::path& baseDir)
+{
+    auto position = [&](const Idx& c) { return vec3(obj.v[3 * (size_t)c.v], obj.v[3 * (size_t)c.v + 1], obj.v[3 * (size_t)c.v + 2]); };
+    const bool fileHasNormals = !obj.vn.empty(), fileHasUvs = !obj.vt.empty();
+    Mesh mesh;
+    std::unordered_map<VertexKey, uint32_t, VertexKeyHash> seen;
+    for (size_t t = first; t < last; ++t) {
+        const Idx* corner = &shape.indices[3 * t];
+        const vec3 p0 = position(corner[0]), p1 = position(corner[1]), p2 = position(corner[2]);
+        const vec3 faceNormal = normalize(cross(p1 - p0, p2 - p0));
+        uint32_t index[3];
+        for (int k = 0; k < 3; ++k) {
+            const Idx& c = corner[k];
+            Vertex v;
+            v.position = position(c);
+            v.normal = (c.vn != -1 && fileHasNormals) ? vec3(obj.vn[3 * (size_t)c.vn], obj.vn[3 * (size_t)c.vn + 1], obj.vn[3 * (size_t)c.vn + 2]) : faceNormal;
+            if (c.vt != -1 && fileHasUvs)
+                v.texCoord = { obj.vt[2 * (size_t)c.vt], obj.vt[2 * (size_t)c.vt + 1] };
+            const auto [slot, fresh] = seen.try_emplace(VertexKey { v }, (uint32_t)mesh.vertices.size());
+            if (fresh)
+                mesh.vertices.push_back(v);
+            index[k] = slot->second;
+        }
+        mesh.triangles.push_back({ index[0], index[1], index[2] });
+    }
+    const int id = shape.materialIds[first];
+    if (id < 0) { /* no material in the file: white, diffuse only */
+        mesh.material.kd = vec3(1.0f);
+        mesh.material.ks = vec3(0.0f);
+        mesh.material.shininess = 1.0f;
+    } else {
+        const ObjMaterial& m = obj.materials[(size_t)id];
+        mesh.material.kd = vec3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
+        mesh.material.ks = vec3(m.specular[0], m.specular[1], m.specular[2]);
+        mesh.material.shininess = m.shininess;
+        mesh.material.transparency = m.dissolve;
+        if (!m.diffuseTex.empty())
+            mesh.material.kdTexture = std::make_shared<Image>(baseDir / m.diffuseTex);
+    }
+    return mesh;
+}
+
 std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNormalize)
 {
     if (!std::filesystem::exists(file)) {
@@ -826,69 +889,10 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
                 throw LoadError();
             }
     }
-    auto pos = [&](int vi) { return vec3(obj.v[3 * (size_t)vi], obj.v[3 * (size_t)vi + 1], obj.v[3 * (size_t)vi + 2]); };
     std::vector<Mesh> out;
-    for (const Shape& shape : obj.shapes) {
-        const size_t nTri = shape.indices.size() / 3;
-        if (nTri == 0)
-            continue;
-        size_t startTriangle = 0;
-        int prevMaterialID = shape.materialIds[0];
-        /* one sub-mesh per run of equal material ids; the "last triangle" test comes first, so a final
-         * triangle with a new material stays in the previous sub-mesh (reference mesh.cpp:78-85) */
-        for (size_t endTriangle = 0; endTriangle < nTri; ++endTriangle) {
-            if (endTriangle == nTri - 1)
-                ++endTriangle;
-            else if (shape.materialIds[endTriangle] == prevMaterialID)
-                continue;
-            else
-                prevMaterialID = shape.materialIds[endTriangle];
-
-            Mesh mesh;
-            std::unordered_map<VertexKey, uint32_t, VertexKeyHash> cache;
-            for (size_t i = startTriangle * 3; i != endTriangle * 3; i += 3) {
-                const vec3 v0 = pos(shape.indices[i].v), v1 = pos(shape.indices[i + 1].v), v2 = pos(shape.indices[i + 2].v);
-                const vec3 geometricNormal = normalize(cross(v1 - v0, v2 - v0));
-                uint32_t tri[3];
-                for (unsigned j = 0; j < 3; ++j) {
-                    const Idx& ix = shape.indices[i + j];
-                    Vertex vertex;
-                    vertex.position = pos(ix.v);
-                    if (ix.vn != -1 && !obj.vn.empty())
-                        vertex.normal = vec3(obj.vn[3 * (size_t)ix.vn], obj.vn[3 * (size_t)ix.vn + 1], obj.vn[3 * (size_t)ix.vn + 2]);
-                    else
-                        vertex.normal = geometricNormal;
-                    if (ix.vt != -1 && !obj.vt.empty())
-                        vertex.texCoord = { obj.vt[2 * (size_t)ix.vt], obj.vt[2 * (size_t)ix.vt + 1] };
-                    auto it = cache.find(VertexKey { vertex });
-                    if (it != cache.end()) {
-                        tri[j] = it->second;
-                    } else {
-                        tri[j] = (uint32_t)mesh.vertices.size();
-                        cache[VertexKey { vertex }] = tri[j];
-                        mesh.vertices.push_back(vertex);
-                    }
-                }
-                mesh.triangles.push_back({ tri[0], tri[1], tri[2] });
-            }
-            const int materialID = shape.materialIds[startTriangle];
-            if (materialID == -1) {
-                mesh.material.kd = vec3(1.0f);
-                mesh.material.ks = vec3(0.0f);
-                mesh.material.shininess = 1.0f;
-            } else {
-                const ObjMaterial& m = obj.materials[(size_t)materialID];
-                mesh.material.kd = vec3(m.diffuse[0], m.diffuse[1], m.diffuse[2]);
-                if (!m.diffuseTex.empty())
-                    mesh.material.kdTexture = std::make_shared<Image>(baseDir / m.diffuseTex);
-                mesh.material.ks = vec3(m.specular[0], m.specular[1], m.specular[2]);
-                mesh.material.shininess = m.shininess;
-                mesh.material.transparency = m.dissolve;
-            }
-            out.push_back(std::move(mesh));
-            startTriangle = endTriangle;
-        }
-    }
+    for (const Shape& shape : obj.shapes)
+        for (const auto& [first, last] : materialRuns(shape.materialIds, shape.indices.size() / 3))
+            out.push_back(subMesh(obj, shape, first, last, baseDir));
     if (centerAndNormalize)
         centerAndScaleToUnit(out);
     return out;
