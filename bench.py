@@ -34,7 +34,7 @@ def workload(name, srt):
     if name in ("dragon", "dragon8k"):
         d = standin.dragon_standin(check=True)
         d["lights"] = standin.dragon_lights()
-        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_MISS_CULL
+        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
         if name == "dragon":
             return d, dict(width=3840, height=2160, features=feat, nsx=4, nsy=2, max_depth=5, cpu_block=1, tile=None,
                            label="dragon stand-in (procedural, 262144 triangles) 3840x2160, 8 spp (4x2 grid), shading + "
@@ -46,12 +46,12 @@ def workload(name, srt):
                              "(point light) + soft shadow (parallelogram light, 100 samples) + mirror recursion (depth cap 5)")
     scene_file = os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz")
     if name == "teapot":
-        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_MISS_CULL
+        feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
         return standin.load_scene_npz(scene_file), dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=4, tile=None,
                                                         label="teapot 15704 triangles 1920x1080, primary + shadow rays")
     if name in ("monkey", "cube_textured"):
         feat = (srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_RECURSIVE | srt.F_NORMAL_INTERP | srt.F_TEXTURE
-                | srt.F_MISS_CULL)
+                | srt.F_MISS_CULL | srt.F_COARSE_SHADOW)
         return standin.load_scene_npz(scene_file), dict(width=1920, height=1080, features=feat, nsx=1, nsy=1, max_depth=5, cpu_block=8, tile=None,
                                                         label=f"{name} 1920x1080, shading + hard shadows + mirror recursion (depth cap 5) + "
                                                               "normal interpolation + texture lookup")
@@ -74,7 +74,7 @@ def cpu_baseline(d, cfg, seconds, threads):
     import orc
     bvh = orc.Bvh(d, orc.F_ACCEL)
     cam = orc.make_camera(cfg["width"], cfg["height"])
-    feat = cfg["features"] & ~orc.F_MISS_CULL
+    feat = cfg["features"] & ~(orc.F_MISS_CULL | orc.F_COARSE_SHADOW)
     rng = np.random.default_rng(2026)
     bw = cfg["cpu_block"]
     nbx, nby = cfg["width"] // bw, cfg["height"] // bw
@@ -133,7 +133,7 @@ def cpu_baseline(d, cfg, seconds, threads):
                          "(64 tiles of 32x32 pixels would take days)" if bw == 1 else "")}
 
 
-PROFILE_KERNELS = {"trace_shadow": "void k_trace_shadow<true, false>", "trace_primary": "void k_trace_primary<true, false>",
+PROFILE_KERNELS = {"trace_shadow": "void k_trace_shadow<true, false, true>", "trace_primary": "void k_trace_primary<true, false>",
                    "trace_secondary": "void k_trace_secondary<true, false>"}
 KERNEL_SOURCES = ("simple-ray-tracer_amd/csrc/srt_kernels.hip", "simple-ray-tracer_amd/csrc/srt_device.h", "include/srt_hip.h")
 
@@ -384,7 +384,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull",
+            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull, shadow queries on coarse boxes",
                        "rays_per_frame": rays_per_frame, "bvh_levels": bvh.num_levels, "bvh_build_upload_s": round(t_build, 3)},
             "roofline": {"bound": "l2", "kernel": dominant, "achieved": achieved, "peak": l2_peak, "unit": "GB/s",
                          "frac": achieved / l2_peak if l2_peak > 0 else None, "traffic": None,

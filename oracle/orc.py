@@ -26,6 +26,7 @@ F_MOTION_BLUR = 1 << 11
 F_DEPTH_OF_FIELD = 1 << 12
 F_ENVIRONMENT = 1 << 13
 F_MISS_CULL = 1 << 16
+F_COARSE_SHADOW = 1 << 17
 
 LIGHT_STRIDE = 22
 

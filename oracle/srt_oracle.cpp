@@ -98,6 +98,10 @@ struct orc_bvh {
     std::vector<Node> nodes;
     std::vector<TriRef> order; /* leaf payload, concatenated in node creation order */
     int levels = 0, leaves = 0;
+    /* shadow queries on coarse boxes (ORC_F_COARSE_SHADOW), filled by coarse_prepare at the end of the build */
+    bool coarse_ok = false;
+    float q_scale[3] = { 1.0f, 1.0f, 1.0f };
+    std::vector<std::array<uint32_t, 3>> cq; /* per node: its box on the 16-bit grid, lower | upper << 16 per axis */
 };
 
 namespace {
@@ -467,6 +471,146 @@ bool intersect(Ctx& c, Ray& ray, HitInfo& hit)
     return closest != FLT_MAX;
 }
 
+/* ---------------------------------------------------------------- shadow queries on coarse boxes
+ * The policy ORC_F_COARSE_SHADOW of the HIP path, restated (it has no counterpart in the reference: like
+ * ORC_F_MISS_CULL it only changes which boxes a query looks into).  A shadow query tests the children of an inner node
+ * on a 16-bit grid over the root box, each box rounded outwards by more than a grid step, with one fused
+ * multiply-add per slab value; the first leaf with an accepted triangle answers it when the hit lies below 0.99 and
+ * hands it to the exact walk otherwise.  Every float operation is written out in the order the kernels use. */
+inline bool fast_dir(float d)
+{
+    uint32_t b;
+    std::memcpy(&b, &d, 4);
+    const uint32_t e = (b >> 23) & 0xFFu;
+    return e >= 107u && e <= 147u;
+}
+inline bool fast_coord(float c)
+{
+    uint32_t b;
+    std::memcpy(&b, &c, 4);
+    b &= 0x7FFFFFFFu;
+    const uint32_t e = b >> 23;
+    return b == 0u || (e >= 87u && e < 147u);
+}
+inline uint32_t coarse_axis(float lo, float hi, float rlo, float s, bool& bad)
+{
+    const float ul = (lo - rlo) * s, uh = (hi - rlo) * s;
+    if (!(ul >= 0.0f && uh <= 65534.0f && ul <= uh))
+        bad = true;
+    const float ql = fmin_std(fmax_std(std::floor(ul), 0.0f), 65535.0f);
+    const float qh = fmin_std(fmax_std(std::ceil(uh) + 2.0f, 0.0f), 65535.0f);
+    return (uint32_t)ql | ((uint32_t)qh << 16);
+}
+void coarse_prepare(orc_bvh& b)
+{
+    b.coarse_ok = false;
+    if (b.nodes.size() < 2) /* no inner node */
+        return;
+    const Box& root = b.nodes.back().box;
+    const float rlo[3] = { root.lo.x, root.lo.y, root.lo.z }, rhi[3] = { root.hi.x, root.hi.y, root.hi.z };
+    for (int k = 0; k < 3; ++k) {
+        const float ext = rhi[k] - rlo[k];
+        b.q_scale[k] = ext > 0.0f ? 65533.0f / ext : 1.0f;
+    }
+    bool bad = false;
+    b.cq.assign(b.nodes.size(), { 0u, 0u, 0u });
+    for (size_t i = 0; i < b.nodes.size(); ++i) {
+        const Box& x = b.nodes[i].box;
+        const float lo[3] = { x.lo.x, x.lo.y, x.lo.z }, hi[3] = { x.hi.x, x.hi.y, x.hi.z };
+        for (int k = 0; k < 3; ++k) {
+            if (!(fast_coord(lo[k]) && fast_coord(hi[k]) && lo[k] <= hi[k]))
+                bad = true; /* outside the ranges of the kernels' fast slab test: they keep the plain policy for the scene */
+            if (i + 1 < b.nodes.size())
+                b.cq[i][k] = coarse_axis(lo[k], hi[k], rlo[k], b.q_scale[k], bad);
+        }
+    }
+    b.coarse_ok = !bad;
+}
+struct CoarseRay {
+    float qi[3], qc[3];
+};
+inline bool coarse_meets(const std::array<uint32_t, 3>& q, const CoarseRay& r)
+{
+    float tl[3], th[3];
+    for (int k = 0; k < 3; ++k) {
+        const float a = std::fmaf((float)(q[k] & 0xFFFFu), r.qi[k], r.qc[k]), b = std::fmaf((float)(q[k] >> 16), r.qi[k], r.qc[k]);
+        tl[k] = fmin_std(a, b), th[k] = fmax_std(a, b);
+    }
+    const float tin = fmax_std(tl[0], fmax_std(tl[1], tl[2]));
+    const float tout = fmin_std(th[0], fmin_std(th[1], th[2]));
+    return !(tin > tout || tout < 0.0f || tin > 1.0f);
+}
+/* Returns true when the coarse walk applies to this ray and leaves the answer in `occluded`; false: the caller walks the
+ * exact way (rays outside the fast ranges, origins far from the root box, and a first hit in [0.99, 1]). */
+bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
+{
+    const orc_bvh& bvh = c.bvh;
+    const float o[3] = { ray.o.x, ray.o.y, ray.o.z }, d[3] = { ray.d.x, ray.d.y, ray.d.z };
+    for (int k = 0; k < 3; ++k)
+        if (!fast_dir(d[k]) || !fast_coord(o[k]))
+            return false;
+    float val;
+    Ray probe = ray;
+    if (!slab(bvh.nodes.back().box, probe, val)) {
+        occluded = false; /* the ray misses the root box */
+        return true;
+    }
+    const Box& root = bvh.nodes.back().box;
+    const float rlo[3] = { root.lo.x, root.lo.y, root.lo.z };
+    CoarseRay cr;
+    for (int k = 0; k < 3; ++k) {
+        const float og = (o[k] - rlo[k]) * bvh.q_scale[k] + 1.0f;
+        cr.qi[k] = 1.0f / (d[k] * bvh.q_scale[k]);
+        cr.qc[k] = -(og * cr.qi[k]);
+        if (!(og >= -65536.0f && og <= 131072.0f))
+            return false;
+    }
+    std::vector<int> stack;
+    int cur = (int)bvh.nodes.size() - 1;
+    for (;;) {
+        const Node& n = bvh.nodes[cur];
+        bool descended = false;
+        if (n.leaf) {
+            Ray r = ray;
+            HitInfo h = like;
+            bool hit = false;
+            for (int k = 0; k < n.b; ++k) {
+                TriRef t = bvh.order[n.a + k];
+                if (leaf_triangle(c, r, h, t.mesh, t.tri))
+                    hit = true;
+            }
+            if (hit) {
+                if (r.t < 0.99f) {
+                    occluded = true;
+                    return true;
+                }
+                return false;
+            }
+        } else {
+            const bool pushL = coarse_meets(bvh.cq[n.a], cr), pushR = coarse_meets(bvh.cq[n.b], cr);
+            if (pushL && pushR) {
+                stack.push_back(n.a);
+                cur = n.b;
+                descended = true;
+            } else if (pushR) {
+                cur = n.b;
+                descended = true;
+            } else if (pushL) {
+                cur = n.a;
+                descended = true;
+            }
+        }
+        if (descended)
+            continue;
+        if (stack.empty()) {
+            occluded = false;
+            return true;
+        }
+        cur = stack.back();
+        stack.pop_back();
+    }
+}
+
 /* ---------------------------------------------------------------- lights */
 
 inline uint32_t mix32(uint32_t h, uint32_t k)
@@ -498,6 +642,11 @@ float visibility(Ctx& c, V3 samplePos, const Ray& ray, const HitInfo& hit)
     nr.o = nr.o + normalize(nr.d) * 0.001f;
     HitInfo h2 = hit;
     c.cnt.shadow_rays += 1;
+    if ((c.features & ORC_F_COARSE_SHADOW) && (c.features & ORC_F_MISS_CULL) && (c.features & ORC_F_ACCEL) && c.bvh.coarse_ok) {
+        bool occluded = false;
+        if (shadow_coarse(c, nr, hit, occluded))
+            return occluded ? 0.0f : 1.0f;
+    }
     /* `newRay.t < 1 - 0.01` compares in double (:62) */
     if (intersect(c, nr, h2) && (double)nr.t < 1 - 0.01)
         return 0.0f;
@@ -728,6 +877,7 @@ orc_bvh* orc_bvh_build(const orc_scene* scene, uint32_t features)
         bd.median_split(0, tris.size(), 0, 0);
     for (const Node& n : b->nodes)
         b->levels = std::max(b->levels, n.level + 1);
+    coarse_prepare(*b);
     return b;
 }
 void orc_bvh_free(orc_bvh* b) { delete b; }

@@ -32,6 +32,7 @@ enum {
     ORC_F_ENVIRONMENT    = 1u << 13, /* extra.enableEnvironmentMapping */
     /* traversal policy: 0 = reference-faithful, 1 = additionally cull every box whose slab test fails */
     ORC_F_MISS_CULL      = 1u << 16,
+    ORC_F_COARSE_SHADOW  = 1u << 17, /* with ORC_F_MISS_CULL: shadow queries test child boxes on a 16-bit grid (see srt_oracle.cpp) */
 };
 
 /* Light record: 22 floats. [0] = type (0 point, 1 segment, 2 parallelogram) then the struct's floats

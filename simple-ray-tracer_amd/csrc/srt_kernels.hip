@@ -67,6 +67,11 @@ struct SceneDev {
     int32_t env_tex;     /* texture index of the environment image, -1 for none */
     uint32_t fast_boxes; /* every box has lower <= upper and coordinates 0 or 2^-40 <= |c| < 2^20: slab_test_fast applies */
     uint64_t n_texels;
+    /* coarse copy of the node array for shadow queries (k_coarsen): per node two uint4, one per child: the child's box
+     * on a 16-bit grid over the root box, rounded outwards (x: lower | upper << 16, y, z), and the child reference */
+    const uint4* cnodes;
+    float q_scale[3];          /* grid coordinate of x: (x - root_lo) * q_scale + 1 */
+    uint32_t coarse_ok;        /* cnodes is usable: every child box lies inside the root box */
 };
 
 struct DevCounters {
@@ -162,6 +167,7 @@ SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& 
 struct Walk {
     f3 o, d;
     RayRcp rr;
+    f3 qi, qc; /* coarse shadow walk: slab value of grid coordinate q is q * qi + qc */
     float T, C;
     uint32_t cur, hitTri;
     int sp;
@@ -895,6 +901,87 @@ SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
     }
 }
 
+/* ---- coarse boxes for shadow queries.
+ * Before its first hit a shadow query asks of a box only whether the ray meets it.  Any box that contains the
+ * child's box answers that question safely (a superset of the nodes is visited, the triangle tests decide), so the
+ * shadow walk reads a coarse copy of the node array: child boxes on a 16-bit grid over the root box, rounded outwards
+ * by more than a grid step - 32 bytes per node instead of 64, two 16-byte loads per visit instead of four, and the
+ * slab values by one fused multiply-add per coordinate in grid space, without the exact division the closest-hit
+ * walks need.  The margin of one grid step on either side covers the rounding of everything involved: the grid
+ * coordinate of a bound or of the origin is off by less than 0.02 steps, a slab value by less than 0.03 steps of
+ * travel along its axis for an origin within one root-box size of the root box (other rays take the exact walk). */
+SRT_DI uint32_t coarse_axis(float lo, float hi, float rlo, float s, bool& bad)
+{
+    const float ul = (lo - rlo) * s, uh = (hi - rlo) * s;
+    if (!(ul >= 0.0f && uh <= 65534.0f && ul <= uh))
+        bad = true; /* outside the root box, or NaN */
+    const float ql = __builtin_fminf(__builtin_fmaxf(__builtin_floorf(ul), 0.0f), 65535.0f);
+    const float qh = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(uh) + 2.0f, 0.0f), 65535.0f);
+    return (uint32_t)ql | ((uint32_t)qh << 16);
+}
+
+__global__ __launch_bounds__(SRT_BLOCK) void k_coarsen(const float4* __restrict__ nodes, uint32_t n, float lox, float loy, float loz, float sx, float sy,
+                                                         float sz, uint4* __restrict__ out, uint32_t* bad_flag)
+{
+    const uint32_t i = blockIdx.x * SRT_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 a = nodes[4ull * i], b = nodes[4ull * i + 1], c = nodes[4ull * i + 2], e = nodes[4ull * i + 3];
+    bool bad = false;
+    uint4 L, R;
+    L.x = coarse_axis(a.x, a.w, lox, sx, bad), L.y = coarse_axis(a.y, b.x, loy, sy, bad), L.z = coarse_axis(a.z, b.y, loz, sz, bad);
+    L.w = __float_as_uint(e.x);
+    R.x = coarse_axis(b.z, c.y, lox, sx, bad), R.y = coarse_axis(b.w, c.z, loy, sy, bad), R.z = coarse_axis(c.x, c.w, loz, sz, bad);
+    R.w = __float_as_uint(e.y);
+    out[2ull * i] = L, out[2ull * i + 1] = R;
+    if (bad)
+        atomicOr(bad_flag, 1u);
+}
+
+/* Grid-space constants of a query's ray; false when the origin is too far from the root box for the margin to hold. */
+SRT_DI bool coarse_ray(const SceneDev& sc, Walk& w)
+{
+    const float ox = (w.o.x - sc.root_lo[0]) * sc.q_scale[0] + 1.0f, oy = (w.o.y - sc.root_lo[1]) * sc.q_scale[1] + 1.0f, oz = (w.o.z - sc.root_lo[2]) * sc.q_scale[2] + 1.0f;
+    w.qi.x = 1.0f / (w.d.x * sc.q_scale[0]), w.qi.y = 1.0f / (w.d.y * sc.q_scale[1]), w.qi.z = 1.0f / (w.d.z * sc.q_scale[2]);
+    w.qc.x = -(ox * w.qi.x), w.qc.y = -(oy * w.qi.y), w.qc.z = -(oz * w.qi.z);
+    const float lim_lo = -65536.0f, lim_hi = 131072.0f;
+    return ox >= lim_lo && ox <= lim_hi && oy >= lim_lo && oy <= lim_hi && oz >= lim_lo && oz <= lim_hi;
+}
+
+SRT_DI bool coarse_meets(const uint4& b, const Walk& w)
+{
+    const float xl = __builtin_fmaf((float)(b.x & 0xFFFFu), w.qi.x, w.qc.x), xh = __builtin_fmaf((float)(b.x >> 16), w.qi.x, w.qc.x);
+    const float yl = __builtin_fmaf((float)(b.y & 0xFFFFu), w.qi.y, w.qc.y), yh = __builtin_fmaf((float)(b.y >> 16), w.qi.y, w.qc.y);
+    const float zl = __builtin_fmaf((float)(b.z & 0xFFFFu), w.qi.z, w.qc.z), zh = __builtin_fmaf((float)(b.z >> 16), w.qi.z, w.qc.z);
+    const float tin = __builtin_fmaxf(__builtin_fminf(xl, xh), __builtin_fmaxf(__builtin_fminf(yl, yh), __builtin_fminf(zl, zh)));
+    const float tout = __builtin_fminf(__builtin_fmaxf(xl, xh), __builtin_fminf(__builtin_fmaxf(yl, yh), __builtin_fmaxf(zl, zh)));
+    return !(tin > tout || tout < 0.0f || tin > 1.0f);
+}
+
+/* swalk_inner on the coarse node array (miss culling only: without it no box is tested at all). */
+template <bool COUNT>
+SRT_DI void swalk_inner_coarse(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
+{
+    if (COUNT) {
+        st.inner += 1;
+        st.box += 2;
+    }
+    const uint4* nd = sc.cnodes + 2ull * w.cur;
+    const uint4 L = nd[0], R = nd[1];
+    const bool pushL = coarse_meets(L, w), pushR = coarse_meets(R, w);
+    if (pushL && pushR) {
+        stk[w.sp * SRT_SHADOW_BLOCK] = L.w;
+        ++w.sp;
+        w.cur = R.w;
+    } else if (pushR) {
+        w.cur = R.w;
+    } else if (pushL) {
+        w.cur = L.w;
+    } else {
+        w.alive = swalk_pop(w, stk);
+    }
+}
+
 /* Leaf visit of the common shadow walk.  Returns 0: no hit, walk on; 1: occluded; 2: first hit in [0.99, 1]. */
 template <bool COUNT>
 SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& st)
@@ -960,7 +1047,7 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
 #ifndef SRT_SHADOW_WAVES
 #define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 6) /* waves per SIMD the register allocation aims at */
 #endif
-template <bool CULL, bool COUNT>
+template <bool CULL, bool COUNT, bool COARSE>
 __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
                                                               const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt,
                                                               unsigned long long* next_chunk)
@@ -1013,6 +1100,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     w.cur = 0, w.sp = 0, w.T = 1.0f, w.C = SRT_FLT_MAX, w.hitTri = 0;
     unsigned long long item = 0;
     bool busy = false;
+    bool redo = false; /* the lane's query cannot take the common walk */
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
         if (!dry && __popcll(idle) >= SRT_REFILL_MIN && used == 64u) {
@@ -1070,8 +1158,11 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                     if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
                         walk_begin<CULL, COUNT, true>(sc, w, org, dir, 1.0f, st);
                         busy = w.alive;
-                        if (!busy)
+                        if (!busy) {
                             vis[item] = 1; /* the ray misses the root box */
+                        } else if (COARSE && !coarse_ray(sc, w)) {
+                            w.alive = false, redo = true; /* answered by the exact walk below */
+                        }
                     } else if (rp.features & SRT_F_ACCEL) {
                         vis[item] = shadow_walk_exact<CULL, COUNT, false>(sc, org, dir, stk, st) ? 0 : 1;
                     } else {
@@ -1087,18 +1178,23 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
         const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
         const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
         const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
-        if ((mInner | mLeaf) == 0) {
+        if ((mInner | mLeaf) == 0 && !(COARSE && __any(redo))) {
             /* nothing in flight: either items remain (every lane is idle, so the next pass refills) or the wave is done */
             if (dry)
                 break;
             continue;
         }
-        int verdict = 0;
+        int verdict = redo ? 2 : 0;
+        redo = false;
         if (__popcll(mInner) * SRT_VOTE_INNER_W >= __popcll(mLeaf) * SRT_VOTE_LEAF_W) {
             if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
                 st.wave_inner += 1;
-            if (atInner)
-                swalk_inner<CULL, COUNT>(sc, w, stk, st);
+            if (atInner) {
+                if (COARSE)
+                    swalk_inner_coarse<COUNT>(sc, w, stk, st);
+                else
+                    swalk_inner<CULL, COUNT>(sc, w, stk, st);
+            }
         } else {
             if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
                 st.wave_leaf += 1;
@@ -1483,7 +1579,7 @@ struct srt_device {
 
 /* Persistent-grid sizes (blocks that fit the GPU at once) of the four queue kernels. */
 struct Grids {
-    int primary = 0, secondary = 0, shadow = 0, shade = 0;
+    int primary = 0, secondary = 0, shadow = 0, shade = 0, shadow_coarse = 0;
 };
 
 struct srt_scene {
@@ -1497,6 +1593,7 @@ struct srt_scene {
 };
 
 static int scene_grids(srt_device* d, srt_scene* sc);
+static int scene_coarsen(srt_scene* sc);
 
 template <typename T>
 static int upload(srt_scene* s, const T* host, size_t count, const T** dev_out)
@@ -1889,7 +1986,8 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const uint32_t n = rp.n_samples;
     const uint32_t sph = shadows_per_hit(sc, rp.features);
     const Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
-    int g_primary = g.primary, g_secondary = g.secondary, g_shadow = g.shadow, g_shade = g.shade;
+    const bool coarse = CULL && (rp.features & SRT_F_COARSE_SHADOW) && sc->view.coarse_ok;
+    int g_primary = g.primary, g_secondary = g.secondary, g_shadow = coarse ? g.shadow_coarse : g.shadow, g_shade = g.shade;
     const int need = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
     if (need < g_primary) g_primary = need;
     if (need < g_secondary) g_secondary = need;
@@ -1931,8 +2029,12 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         float4* nxt = wk.path[(depth + 1) & 1];
         if (sph) {
             mark(d, st, 4, timing);
-            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq, hq_count + depth, cur,
-                vis, sph, d->counters + 4, wk.chunk_counters + depth);
+            if (coarse)
+                hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, CULL>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq,
+                    hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
+            else
+                hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, false>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq,
+                    hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
         }
         mark(d, st, 2, timing);
         hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
@@ -1985,15 +2087,51 @@ static int fill_grids(srt_device* d, srt_scene* sc)
     Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
     int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, stack_bytes(sc), &g.primary);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, stack_bytes(sc), &g.secondary);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT>, shadow_lds_bytes(sc), &g.shadow, SRT_SHADOW_BLOCK);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, false>, shadow_lds_bytes(sc), &g.shadow, SRT_SHADOW_BLOCK);
+    if (rc == SRT_OK && CULL) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, true>, shadow_lds_bytes(sc), &g.shadow_coarse, SRT_SHADOW_BLOCK);
     if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g.shade);
     return rc;
+}
+
+/* The coarse node array of a freshly uploaded or built scene (see coarse_axis). */
+static int scene_coarsen(srt_scene* s)
+{
+    SceneDev& v = s->view;
+    v.cnodes = nullptr, v.coarse_ok = 0;
+    for (int k = 0; k < 3; ++k) {
+        const float ext = v.root_hi[k] - v.root_lo[k];
+        v.q_scale[k] = ext > 0.0f ? 65533.0f / ext : 1.0f;
+    }
+    if (!v.n_nodes || !v.fast_boxes)
+        return SRT_OK;
+    void *p = nullptr, *flag = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t)v.n_nodes * 32));
+    s->allocs.push_back(p);
+    HIPCHK(hipMalloc(&flag, 4));
+    uint32_t bad = 0;
+    hipError_t e = hipMemset(flag, 0, 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_coarsen, dim3((v.n_nodes + SRT_BLOCK - 1) / SRT_BLOCK), dim3(SRT_BLOCK), 0, 0, v.nodes, v.n_nodes, v.root_lo[0], v.root_lo[1], v.root_lo[2],
+            v.q_scale[0], v.q_scale[1], v.q_scale[2], (uint4*)p, (uint32_t*)flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(&bad, flag, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(flag);
+    if (e != hipSuccess)
+        return fail(SRT_ERR_HIP, "coarse node array: %s", hipGetErrorString(e));
+    v.cnodes = (const uint4*)p;
+    v.coarse_ok = bad ? 0u : 1u;
+    return SRT_OK;
 }
 
 /* Called once per scene upload, so that no render call has to query occupancies. */
 static int scene_grids(srt_device* d, srt_scene* sc)
 {
-    int rc = fill_grids<false, false>(d, sc);
+    int rc = scene_coarsen(sc);
+    if (rc != SRT_OK)
+        return rc;
+    rc = fill_grids<false, false>(d, sc);
     if (rc == SRT_OK) rc = fill_grids<false, true>(d, sc);
     if (rc == SRT_OK) rc = fill_grids<true, false>(d, sc);
     if (rc == SRT_OK) rc = fill_grids<true, true>(d, sc);

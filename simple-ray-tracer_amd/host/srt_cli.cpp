@@ -77,6 +77,7 @@ int main(int argc, char** argv)
 
         RenderOptions options;
         options.referenceTraversal = config.backend.referenceTraversal;
+        options.exactShadowBoxes = config.backend.exactShadowBoxes;
         options.maxDepth = config.backend.maxDepth;
         options.seed = config.backend.seed;
         /* The reference starts one host thread per camera; the frames of one GPU are stream ordered, so they are

@@ -147,7 +147,7 @@ std::ostream& operator<<(std::ostream& os, const Config& config)
     r.entry("num_rays", b.numRays);
     r.entry("enable_soft_shadow", b.enableSoftShadow);
     r.entry("enable_transparency", b.enableTransparency);
-    r.entry("traversal", b.referenceTraversal ? "reference" : "miss-cull");
+    r.entry("traversal", b.referenceTraversal ? "reference" : b.exactShadowBoxes ? "miss-cull-exact" : "miss-cull");
     r.entry("max_depth", b.maxDepth);
     r.entry("seed", b.seed);
     os << "    - motion blur: samples " << b.mbSamples << ", time0 " << b.time0 << ", time1 " << b.time1 << ", direction " << Bracketed { b.direction } << std::endl
@@ -327,8 +327,10 @@ static Config fromTable(const toml::Value& table)
         if (backend["traversal"].kind == toml::Value::String) {
             if (backend["traversal"].s == "reference")
                 b.referenceTraversal = true;
+            else if (backend["traversal"].s == "miss-cull-exact")
+                b.exactShadowBoxes = true;
             else if (backend["traversal"].s != "miss-cull")
-                throw std::runtime_error("configuration: mi355x.traversal must be \"reference\" or \"miss-cull\"");
+                throw std::runtime_error("configuration: mi355x.traversal must be \"reference\", \"miss-cull\" or \"miss-cull-exact\"");
         }
     }
     return config;

@@ -27,7 +27,8 @@ struct BackendConfig {
     int numRays = 1;                 /* the reference's command-line path always renders with numRays = 1 (src/main.cpp:45,476) */
     bool enableSoftShadow = false;   /* the reference's reader never sets Features::enableSoftShadow */
     bool enableTransparency = false; /* nor extra.enableTransparency (only its viewer's check box does) */
-    bool referenceTraversal = false; /* "traversal" = "reference" | "miss-cull" */
+    bool referenceTraversal = false; /* "traversal" = "reference" | "miss-cull" | "miss-cull-exact" */
+    bool exactShadowBoxes = false;   /* "miss-cull-exact": shadow queries on full-precision boxes */
     int maxDepth = 5;
     uint32_t seed = 0;
     /* The Scene's motion-blur / depth-of-field variables, which the reference only sets from sliders of its viewer

@@ -55,7 +55,7 @@ int currentDevice() { return t_gpu; }
 float radians(float degrees) { return degrees * 0.01745329251994329576923690768489f; }
 vec3 radians(const vec3& d) { return { radians(d.x), radians(d.y), radians(d.z) }; }
 
-uint32_t featureMask(const Features& f, bool referenceTraversal)
+uint32_t featureMask(const Features& f, bool referenceTraversal, bool exactShadowBoxes)
 {
     uint32_t m = 0;
     if (f.enableShading) m |= SRT_F_SHADING;
@@ -70,7 +70,7 @@ uint32_t featureMask(const Features& f, bool referenceTraversal)
     if (f.extra.enableMotionBlur) m |= SRT_F_MOTION_BLUR;
     if (f.extra.enableDepthOfField) m |= SRT_F_DEPTH_OF_FIELD;
     if (f.extra.enableEnvironmentMapping) m |= SRT_F_ENVIRONMENT;
-    if (!referenceTraversal) m |= SRT_F_MISS_CULL;
+    if (!referenceTraversal) m |= SRT_F_MISS_CULL | (exactShadowBoxes ? 0u : SRT_F_COARSE_SHADOW);
     return m;
 }
 
@@ -743,7 +743,7 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
     const ivec2 res = screen.resolution();
     srt_render_params p {};
     p.camera = camera.deviceCamera(res.x, res.y);
-    p.features = featureMask(features, opt.referenceTraversal);
+    p.features = featureMask(features, opt.referenceTraversal, opt.exactShadowBoxes);
     p.samples_x = opt.samplesX > 0 ? opt.samplesX : numRays;
     p.samples_y = opt.samplesY > 0 ? opt.samplesY : numRays;
     p.max_depth = opt.maxDepth;

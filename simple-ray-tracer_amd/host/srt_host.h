@@ -197,6 +197,7 @@ srt_device* deviceFor(int deviceKey);
 
 struct RenderOptions {
     bool referenceTraversal = false; /* true: the reference's exact visiting rule (full-tree shadow walks) */
+    bool exactShadowBoxes = false;   /* true: shadow queries test the full-precision child boxes (SRT_F_MISS_CULL alone) */
     int maxDepth = 5;                /* the reference hard-codes 5 (src/render.cpp:107) */
     int samplesX = 0, samplesY = 0;  /* 0: numRays x numRays as in the reference */
     uint32_t seed = 0;
@@ -342,7 +343,7 @@ vec3 radians(const vec3& degrees);
 
 /* ---- frame */
 
-uint32_t featureMask(const Features& features, bool referenceTraversal);
+uint32_t featureMask(const Features& features, bool referenceTraversal, bool exactShadowBoxes = false);
 
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features,
                       const float& threshold = 0, const int& boxSize = 0, const int& numRays = 5);

@@ -234,6 +234,9 @@ FEATURE_SETS = {
 }
 
 
+POLICY = {"reference": 0, "cull": srt.F_MISS_CULL, "coarse": srt.F_MISS_CULL | srt.F_COARSE_SHADOW}
+
+
 def _compare_frames(got, want, what):
     assert np.array_equal(got["mesh"], want["mesh"]) and np.array_equal(got["tri"], want["tri"]), what
     assert_bits_equal(got["t"], want["t"], what + " primary t")
@@ -245,14 +248,14 @@ def _compare_frames(got, want, what):
 
 @pytest.mark.parametrize("name,res", [("cube_textured", (160, 120)), ("cornell", (128, 128)), ("monkey", (128, 96)), ("teapot", (96, 54))])
 @pytest.mark.parametrize("fs", list(FEATURE_SETS))
-@pytest.mark.parametrize("policy", ["reference", "cull"])
+@pytest.mark.parametrize("policy", ["reference", "cull", "coarse"])
 def test_render_matches_oracle(orc, pair, name, res, fs, policy):
     if fs == "no_accel" and name == "teapot":
         pytest.skip("brute force over 15 704 triangles: covered by the smaller scenes")
     if policy == "reference" and name == "teapot" and fs not in ("albedo", "hard_shadow"):
         pytest.skip("full-tree shadow walks on the oracle: two feature sets are enough at this size")
     ob, gb = pair(name)
-    feat = FEATURE_SETS[fs] | (srt.F_MISS_CULL if policy == "cull" else 0)
+    feat = FEATURE_SETS[fs] | POLICY[policy]
     want = ob.render(orc.make_camera(*res), feat)
     got = gb.render(srt.make_camera(*res), feat)
     _compare_frames(got, want, f"{name}/{fs}/{policy}")
@@ -337,12 +340,30 @@ def test_many_lights(orc, pair):
         assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] > 0
 
 
-@pytest.mark.parametrize("policy", ["reference", "cull"])
+@pytest.mark.parametrize("name,res", [("cornell_parallelogram", (96, 96)), ("monkey", (128, 96)), ("teapot", (96, 54)), ("cube", (80, 60))])
+def test_coarse_shadow_boxes(orc, pair, name, res):
+    """Shadow queries on the half-size node array (16-bit outward-rounded child boxes): the frame with soft and hard
+    shadows and reflections equals the oracle's under the same policy, and equals the frame on full-precision boxes
+    bit for bit - a coarse box can only add nodes to a query's walk, the triangle tests decide."""
+    ob, gb = pair(name)
+    base = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_RECURSIVE | srt.F_MISS_CULL
+    want = ob.render(orc.make_camera(*res), base | srt.F_COARSE_SHADOW)
+    got = gb.render(srt.make_camera(*res), base | srt.F_COARSE_SHADOW, flags=srt.RENDER_STATS)
+    exact = gb.render(srt.make_camera(*res), base, flags=srt.RENDER_STATS)
+    _compare_frames(got, want, f"{name}/coarse shadow boxes")
+    assert np.array_equal(got["rgb"].view(np.uint32), exact["rgb"].view(np.uint32))
+    gc, ec = got["counters"], exact["counters"]
+    assert gc["shadow_rays"] == ec["shadow_rays"] == want["counters"]["shadow_rays"] > 0
+    # a superset of the nodes, by a small margin
+    assert ec["inner_visits"] <= gc["inner_visits"] <= 1.1 * ec["inner_visits"] and ec["tri_tests"] <= gc["tri_tests"] <= 1.1 * ec["tri_tests"]
+
+
+@pytest.mark.parametrize("policy", ["reference", "cull", "coarse"])
 @pytest.mark.parametrize("name,behind", [("cornell", 0.004), ("monkey", 0.0005)])
 def test_shadow_hit_just_before_light(orc, pair, name, behind, policy):
     # Lights just behind a surface: seen from far enough away the surface is hit at 0.99 <= t <= 1, which the
     # reference does not count as occlusion (light.cpp:60) but walks on from with the smaller t.
-    cull = srt.F_MISS_CULL if policy == "cull" else 0
+    cull = srt.F_MISS_CULL if policy != "reference" else 0
     ob, _ = pair(name)
     cam = orc.make_camera(64, 48)
     rays = orc.camera_rays(cam, orc.pixel_ndc(64, 48).reshape(-1, 2))
@@ -370,7 +391,7 @@ def test_shadow_hit_just_before_light(orc, pair, name, behind, policy):
         assert_bits_equal(got["t"], want["t"], "shadow-ray t")
         near += int(((want["hit"] != 0) & (want["t"] >= 0.99)).sum())
     assert near > 30, near
-    feat = SH | srt.F_HARD_SHADOW | srt.F_RECURSIVE | cull
+    feat = SH | srt.F_HARD_SHADOW | srt.F_RECURSIVE | POLICY[policy]
     want = ob.render(orc.make_camera(64, 48), feat)
     got = gb.render(srt.make_camera(64, 48), feat)
     _compare_frames(got, want, f"lights just behind surfaces, {name}/{policy}")

@@ -26,7 +26,7 @@ for d in sorted(glob.glob(base + "/g*/")):
         rows += list(sqlite3.connect(f).execute("select dispatch_id, kernel_name, counter_name, value from counters_collection"))
     per = collections.defaultdict(float)
     for disp, kern, ctr, val in rows:
-        if "k_trace_shadow<true, false>" in kern or "k_trace_shadowILb1ELb0" in kern:
+        if "k_trace_shadow<true, false" in kern or "k_trace_shadowILb1ELb0" in kern:
             per[(disp, ctr)] += val
     for (disp, ctr), val in per.items():
         agg[ctr] += val
