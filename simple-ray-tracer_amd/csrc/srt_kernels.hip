@@ -72,6 +72,9 @@ struct SceneDev {
     const uint4* cnodes;
     float q_scale[3];          /* grid coordinate of x: (x - root_lo) * q_scale + 1 */
     uint32_t coarse_ok;        /* cnodes is usable: every child box lies inside the root box */
+    /* the part of a triangle record the shadow walk reads (plane and vertices: its first four quarters), 64 bytes per
+     * triangle, so that the two triangles of a leaf share one 128-byte cache line instead of lying across two or three */
+    const float4* stris;
 };
 
 struct DevCounters {
@@ -768,7 +771,10 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #ifndef SRT_SHADOW_BLOCK
 #define SRT_SHADOW_BLOCK 256
 #endif
-#define SRT_LDS_LIGHTS 16u /* lights a block keeps in LDS; further ones are read from global memory */
+#define SRT_LDS_LIGHTS 16u
+#ifndef SRT_SHADOW_CHUNK_MAX
+#define SRT_SHADOW_CHUNK_MAX 1024u /* most shadow queries a wave draws from the shared counter at a time */
+#endif /* lights a block keeps in LDS; further ones are read from global memory */
 
 /* ---- shadow queries: a walk with four-byte stack entries.
  * Until a shadow query accepts its first hit, C is FLT_MAX: no pop test can skip a pending sibling, and the
@@ -938,6 +944,13 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_coarsen(const float4* __restrict_
         atomicOr(bad_flag, 1u);
 }
 
+__global__ __launch_bounds__(SRT_BLOCK) void k_shadow_tris(const float4* __restrict__ tris, uint64_t n_quarters, float4* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * SRT_BLOCK + threadIdx.x; /* one quarter of the compact record */
+    if (i < n_quarters)
+        out[i] = tris[6ull * (i >> 2) + (i & 3u)];
+}
+
 /* Grid-space constants of a query's ray; false when the origin is too far from the root box for the margin to hold. */
 SRT_DI bool coarse_ray(const SceneDev& sc, Walk& w)
 {
@@ -1002,9 +1015,9 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
      * whose plane is met within the ray's t, so a pair costs two waits instead of four.  The second triangle is then
      * accepted against the t the first one left, as when they are tested one after the other. */
     for (uint32_t k = 0; k < cnt; k += 2) {
-        const float4* r0 = sc.tris + 6ull * (first + k);
+        const float4* r0 = sc.stris + 4ull * (first + k);
         const bool two = k + 1 < cnt;
-        const float4* r1 = two ? r0 + 6 : r0;
+        const float4* r1 = two ? r0 + 4 : r0;
         if (COUNT)
             st.tri += two ? 2 : 1;
         float nt0, nt1;
@@ -1040,12 +1053,12 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
  *
  * Shadow queries differ wildly in length (an occluded one stops at its first hit, a free one walks every box
  * around its origin), so a wave that started 64 of them together would soon run mostly empty.  Instead a
- * lane whose query ends hands in its answer and, as soon as 24 lanes of the wave are idle (SRT_REFILL_MIN; 16 to 32 measure within 2 %), the idle lanes are
- * given the wave's next items.  A wave draws its items from 64-item chunks at a fixed stride, consecutive items
- * going to consecutive idle lanes, so its lanes keep working on neighbouring samples of the same few hits
- * (same origin, nearby targets on the light). */
+ * lane whose query ends hands in its answer and, as soon as 24 lanes of the wave are idle (SRT_REFILL_MIN; 16 to 32
+ * measure within 2 %), the idle lanes are given the wave's next items.  A wave draws its items in chunks of
+ * consecutive items, consecutive items going to consecutive idle lanes, so its lanes keep working on neighbouring
+ * samples of the same few hits (same origin, nearby targets on the light). */
 #ifndef SRT_SHADOW_WAVES
-#define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 6) /* waves per SIMD the register allocation aims at */
+#define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 7) /* waves per SIMD the register allocation aims at */
 #endif
 template <bool CULL, bool COUNT, bool COARSE>
 __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,
@@ -1065,11 +1078,22 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     uint32_t nShadow = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long n = (unsigned long long)(*hq_count) * shadows_per_hit;
-    /* Items are handed out in chunks of 64.  A wave's first chunk follows from its position in the grid; every
+    /* Items are handed out in chunks.  A wave's first chunk follows from its position in the grid; every
      * further one is drawn from a counter all waves share (one atomic per chunk), so waves that happen to get
      * long queries simply draw fewer chunks: with a fixed stride instead, the slowest wave's share decided the
      * launch time (measured 220 -> 200 ms on the dragon frame). */
-    const unsigned long long first_shared = (unsigned long long)gridDim.x * SRT_SHADOW_BLOCK;
+    /* Chunk size: every draw is an atomic on one address, and all waves of the GPU drawing 64 items at a time kept that
+     * address busier than the caches (14 M draws per dragon frame: the launch took 172 ms whatever else was changed,
+     * 150 ms with 256 items per draw).  Large launches therefore draw up to 1024 items at a time, small ones keep 64 so
+     * that their few items still spread over the waves: at least 16 draws per wave. */
+    uint32_t chunkItems = 64u;
+    {
+        const unsigned long long per = n / ((unsigned long long)gridDim.x * (SRT_SHADOW_BLOCK / 64) * 16ull);
+        while (chunkItems < SRT_SHADOW_CHUNK_MAX && 2ull * chunkItems <= per)
+            chunkItems *= 2u;
+        chunkItems = __builtin_amdgcn_readfirstlane(chunkItems);
+    }
+    const unsigned long long first_shared = (unsigned long long)gridDim.x * (SRT_SHADOW_BLOCK / 64) * chunkItems;
     /* chunk, used and dry are the same in all lanes of a wave; reading them through readfirstlane tells the compiler
      * so, and the refill conditions and the loop's exit become scalar branches instead of exec-mask bookkeeping
      * in every trip */
@@ -1080,10 +1104,10 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     auto grab = [&]() {
         unsigned long long base = 0;
         if (lane == 0)
-            base = atomicAdd(next_chunk, 64ull);
+            base = atomicAdd(next_chunk, (unsigned long long)chunkItems);
         return first_shared + uniform(base); /* lane 0 is the first active lane: no lane leaves the loop before the wave does */
     };
-    unsigned long long chunk = uniform((unsigned long long)blockIdx.x * SRT_SHADOW_BLOCK + (threadIdx.x & ~63u));
+    unsigned long long chunk = uniform(((unsigned long long)blockIdx.x * (SRT_SHADOW_BLOCK / 64) + (threadIdx.x >> 6)) * chunkItems);
     /* hit and sample number of a chunk's first item: one 64-bit division per chunk; the items of the chunk then
      * need 32-bit arithmetic only */
     uint32_t hitBase = 0, sampleBase = 0;
@@ -1103,7 +1127,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     bool redo = false; /* the lane's query cannot take the common walk */
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
-        if (!dry && __popcll(idle) >= SRT_REFILL_MIN && used == 64u) {
+        if (!dry && __popcll(idle) >= SRT_REFILL_MIN && used == chunkItems) {
             chunk = grab();
             locate(chunk);
             used = 0;
@@ -1115,14 +1139,14 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             unsigned long long mine = chunk + pos;
             uint32_t hb = hitBase, within = sampleBase + pos;
             used += cnt;
-            if (used > 64u) {
+            if (used > chunkItems) {
                 /* the idle lanes outnumber what is left of the chunk: the rest come from the next one */
                 chunk = grab();
                 locate(chunk);
-                used -= 64u;
-                if (pos >= 64u) {
-                    mine = chunk + (pos - 64u);
-                    hb = hitBase, within = sampleBase + (pos - 64u);
+                used -= chunkItems;
+                if (pos >= chunkItems) {
+                    mine = chunk + (pos - chunkItems);
+                    hb = hitBase, within = sampleBase + (pos - chunkItems);
                 }
             }
             if (!busy && mine < n) {
@@ -2097,7 +2121,19 @@ static int fill_grids(srt_device* d, srt_scene* sc)
 static int scene_coarsen(srt_scene* s)
 {
     SceneDev& v = s->view;
-    v.cnodes = nullptr, v.coarse_ok = 0;
+    v.cnodes = nullptr, v.coarse_ok = 0, v.stris = nullptr;
+    {
+        void* q = nullptr;
+        HIPCHK(hipMalloc(&q, v.n_tris ? (size_t)v.n_tris * 64 : 64));
+        s->allocs.push_back(q);
+        if (v.n_tris) {
+            const uint64_t nq = (uint64_t)v.n_tris * 4;
+            hipLaunchKernelGGL(k_shadow_tris, dim3((unsigned)((nq + SRT_BLOCK - 1) / SRT_BLOCK)), dim3(SRT_BLOCK), 0, 0, v.tris, nq, (float4*)q);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipDeviceSynchronize());
+        }
+        v.stris = (const float4*)q;
+    }
     for (int k = 0; k < 3; ++k) {
         const float ext = v.root_hi[k] - v.root_lo[k];
         v.q_scale[k] = ext > 0.0f ? 65533.0f / ext : 1.0f;
