@@ -222,6 +222,7 @@ def main():
                     "traffic and cache counters from; default: the newest profiles/*_summary.txt taken with the current kernel sources")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-shadow-boxes", action="store_true", help="shadow queries on the full-precision node array (F_MISS_CULL alone) instead of the coarse one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--lanes", type=int, default=None, help="back-end contexts (each with its stream) a tiled frame alternates between "
@@ -253,6 +254,9 @@ def main():
     srt = importlib.import_module("simple-ray-tracer_amd")
     srt.set_device(local_rank)
     d, cfg = workload(args.workload, srt)
+    if args.exact_shadow_boxes:
+        cfg["features"] &= ~srt.F_COARSE_SHADOW
+        PROFILE_KERNELS["trace_shadow"] = "void k_trace_shadow<true, false, false>"
     W, H = cfg["width"], cfg["height"]
     t_build = time.perf_counter()
     bvh = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
@@ -384,7 +388,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull, shadow queries on coarse boxes",
+            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull" + (", shadow queries on coarse boxes" if cfg["features"] & srt.F_COARSE_SHADOW else ""),
                        "rays_per_frame": rays_per_frame, "bvh_levels": bvh.num_levels, "bvh_build_upload_s": round(t_build, 3)},
             "roofline": {"bound": "l2", "kernel": dominant, "achieved": achieved, "peak": l2_peak, "unit": "GB/s",
                          "frac": achieved / l2_peak if l2_peak > 0 else None, "traffic": None,

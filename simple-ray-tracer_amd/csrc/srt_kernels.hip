@@ -72,9 +72,6 @@ struct SceneDev {
     const uint4* cnodes;
     float q_scale[3];          /* grid coordinate of x: (x - root_lo) * q_scale + 1 */
     uint32_t coarse_ok;        /* cnodes is usable: every child box lies inside the root box */
-    /* the part of a triangle record the shadow walk reads (plane and vertices: its first four quarters), 64 bytes per
-     * triangle, so that the two triangles of a leaf share one 128-byte cache line instead of lying across two or three */
-    const float4* stris;
 };
 
 struct DevCounters {
@@ -772,6 +769,12 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #define SRT_SHADOW_BLOCK 256
 #endif
 #define SRT_LDS_LIGHTS 16u
+#ifndef SRT_SVOTE_INNER_W
+/* Vote weights of the shadow walk, box step : leaf step (dragon / teapot shadow launch: 1:2 141.4 / 0.752 ms, 3:4 138.7 /
+ * 0.746, 1:1 139.2 / 0.759, 4:3 141.6 / 0.767) */
+#define SRT_SVOTE_INNER_W 3
+#define SRT_SVOTE_LEAF_W 4
+#endif
 #ifndef SRT_SHADOW_CHUNK_MAX
 #define SRT_SHADOW_CHUNK_MAX 1024u /* most shadow queries a wave draws from the shared counter at a time */
 #endif /* lights a block keeps in LDS; further ones are read from global memory */
@@ -944,13 +947,6 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_coarsen(const float4* __restrict_
         atomicOr(bad_flag, 1u);
 }
 
-__global__ __launch_bounds__(SRT_BLOCK) void k_shadow_tris(const float4* __restrict__ tris, uint64_t n_quarters, float4* __restrict__ out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * SRT_BLOCK + threadIdx.x; /* one quarter of the compact record */
-    if (i < n_quarters)
-        out[i] = tris[6ull * (i >> 2) + (i & 3u)];
-}
-
 /* Grid-space constants of a query's ray; false when the origin is too far from the root box for the margin to hold. */
 SRT_DI bool coarse_ray(const SceneDev& sc, Walk& w)
 {
@@ -1015,9 +1011,9 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
      * whose plane is met within the ray's t, so a pair costs two waits instead of four.  The second triangle is then
      * accepted against the t the first one left, as when they are tested one after the other. */
     for (uint32_t k = 0; k < cnt; k += 2) {
-        const float4* r0 = sc.stris + 4ull * (first + k);
+        const float4* r0 = sc.tris + 6ull * (first + k);
         const bool two = k + 1 < cnt;
-        const float4* r1 = two ? r0 + 4 : r0;
+        const float4* r1 = two ? r0 + 6 : r0;
         if (COUNT)
             st.tri += two ? 2 : 1;
         float nt0, nt1;
@@ -1210,7 +1206,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
         }
         int verdict = redo ? 2 : 0;
         redo = false;
-        if (__popcll(mInner) * SRT_VOTE_INNER_W >= __popcll(mLeaf) * SRT_VOTE_LEAF_W) {
+        if (__popcll(mInner) * SRT_SVOTE_INNER_W >= __popcll(mLeaf) * SRT_SVOTE_LEAF_W) {
             if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
                 st.wave_inner += 1;
             if (atInner) {
@@ -2121,19 +2117,7 @@ static int fill_grids(srt_device* d, srt_scene* sc)
 static int scene_coarsen(srt_scene* s)
 {
     SceneDev& v = s->view;
-    v.cnodes = nullptr, v.coarse_ok = 0, v.stris = nullptr;
-    {
-        void* q = nullptr;
-        HIPCHK(hipMalloc(&q, v.n_tris ? (size_t)v.n_tris * 64 : 64));
-        s->allocs.push_back(q);
-        if (v.n_tris) {
-            const uint64_t nq = (uint64_t)v.n_tris * 4;
-            hipLaunchKernelGGL(k_shadow_tris, dim3((unsigned)((nq + SRT_BLOCK - 1) / SRT_BLOCK)), dim3(SRT_BLOCK), 0, 0, v.tris, nq, (float4*)q);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipDeviceSynchronize());
-        }
-        v.stris = (const float4*)q;
-    }
+    v.cnodes = nullptr, v.coarse_ok = 0;
     for (int k = 0; k < 3; ++k) {
         const float ext = v.root_hi[k] - v.root_lo[k];
         v.q_scale[k] = ext > 0.0f ? 65533.0f / ext : 1.0f;
