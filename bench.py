@@ -58,10 +58,10 @@ def workload(name, srt):
     raise SystemExit(f"unknown workload {name}")
 
 
-def algorithmic_bytes(c):
-    """64 B per inner-node visit + 36 B per triangle test + 48 B of ray I/O per query + 64 B of attributes per
-    shaded hit."""
-    return 64 * c["inner_visits"] + 36 * c["tri_tests"] + 48 * (c["path_rays"] + c["shadow_rays"]) + 64 * c["shaded_hits"]
+def algorithmic_bytes(c, node_bytes=64):
+    """node_bytes per inner-node visit (64: a node record with both child boxes; 32: the coarse record the shadow walk
+    reads) + 36 B per triangle test + 48 B of ray I/O per query + 64 B of attributes per shaded hit."""
+    return node_bytes * c["inner_visits"] + 36 * c["tri_tests"] + 48 * (c["path_rays"] + c["shadow_rays"]) + 64 * c["shaded_hits"]
 
 
 def cpu_baseline(d, cfg, seconds, threads):
@@ -371,7 +371,11 @@ def main():
         launches_timed = max(times[dominant]["launches"], 1)
         avg_ms = times[dominant]["ms"] / launches_timed
         launches_per_frame = launches_timed / args.steps
-        bytes_per_launch = algorithmic_bytes(fam[dominant]) / max(launches_per_frame, 1e-9)
+        # the shadow walk on coarse boxes reads 32-byte node records; every other walk the 64-byte ones
+        coarse = bool(cfg["features"] & srt.F_COARSE_SHADOW)
+        node_bytes = {n: (32 if (n == "trace_shadow" and coarse) else 64) for n in fam}
+        bytes_per_launch = algorithmic_bytes(fam[dominant], node_bytes[dominant]) / max(launches_per_frame, 1e-9)
+        full_record_bytes_per_launch = algorithmic_bytes(fam[dominant]) / max(launches_per_frame, 1e-9)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # The records the traversal kernels read (nodes + triangle stream, 33 MB on the dragon stand-in) never leave
         # the caches, so the ceiling that prices them is a cache's gather rate, not HBM: measured here, on this GPU,
@@ -401,10 +405,15 @@ def main():
                          "avg_launch_ms": avg_ms, "launches_timed": launches_timed,
                          "concurrent_lanes": len(lanes),  # > 1: launches of different tiles overlap, so do their timed intervals
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "node_record_bytes": node_bytes[dominant],
+                         # the same visits priced at 64 bytes per node visit, the full record (what a walk on uncompressed
+                         # nodes would have to read for them): comparable across node encodings, may exceed the gather peak
+                         "at_full_node_records": {"achieved": full_record_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+                                                  "over_peak": full_record_bytes_per_launch / (avg_ms * 1e-3) / 1e9 / l2_peak if avg_ms > 0 and l2_peak > 0 else None},
                          "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times},
                          # the same achieved / peak ratio for every traversal family (per frame: bytes over summed launch time)
-                         "by_kernel": {n: {"achieved": algorithmic_bytes(fam[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9,
-                                           "frac": algorithmic_bytes(fam[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9 / l2_peak}
+                         "by_kernel": {n: {"achieved": algorithmic_bytes(fam[n], node_bytes[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9,
+                                           "frac": algorithmic_bytes(fam[n], node_bytes[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9 / l2_peak}
                                        for n in times if n.startswith("trace_") and times[n]["ms"] > 0 and l2_peak > 0},
                          "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]}},
         }

@@ -4,7 +4,7 @@
 T=$1
 R=$GRAFT_REPO_ROOT
 cd $R
-bash tools/profile.sh ${T}_dragon || exit 1
+[ -n "$SKIP_PROFILE" ] || bash tools/profile.sh ${T}_dragon || exit 1   # SKIP_PROFILE=1: bench lines only
 line() { grep '^{"metric"' | tail -1; }
 timeout -k 10 300 python3 -u bench.py 2> gpurun_out/${T}_bench_dragon.err | line > gpurun_out/${T}_bench_dragon.jsonl || exit 1
 echo "dragon done"
