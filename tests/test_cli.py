@@ -126,6 +126,10 @@ enable_soft_shadow = true
     assert "- field_of_view: 45\n      distance_from_look_at: 3\n      look_at: [0, 0, 0]\n      rotation: [10, -2.5, 0]" in text
     assert "look_at: [0.5, 0.25, 0.125]" in text
     assert "- num_rays: 3" in text and "- traversal: reference" in text and "+ mi355x: \n    - gpu: 0\n    - num_rays: 3\n    - enable_soft_shadow: true" in text
+    assert "- traversal: miss-cull-exact" in srt.config_describe(doc.replace("'reference'", "'miss-cull-exact'"))
+    assert "- traversal: miss-cull\n" in srt.config_describe(doc.replace("traversal = 'reference'\n", ""))
+    with pytest.raises(srt.SrtError, match="miss-cull-exact"):
+        srt.config_describe(doc.replace("'reference'", "'fastest'"))
 
 
 def test_cli_check_mode(tmp_path):
