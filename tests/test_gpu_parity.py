@@ -662,8 +662,8 @@ def test_sah_binned_tree(orc, scenes, gpu, name):
         got, _, _ = gb.intersect(rays, feat)
         assert np.array_equal(got["hit"], want["hit"]) and np.array_equal(got["tri"], want["tri"])
         assert_bits_equal(got["t"], want["t"], "t")
-    feat = FEATURE_SETS["recursive"] | srt.F_MISS_CULL
-    _compare_frames(gb.render(srt.make_camera(96, 64), feat), ob.render(orc.make_camera(96, 64), feat), f"{name} SAH tree")
+    for feat in (FEATURE_SETS["recursive"] | srt.F_MISS_CULL, FEATURE_SETS["recursive"] | srt.F_SOFT_SHADOW | srt.F_MISS_CULL | srt.F_COARSE_SHADOW):
+        _compare_frames(gb.render(srt.make_camera(96, 64), feat), ob.render(orc.make_camera(96, 64), feat), f"{name} SAH tree")
 
 
 def _see_through_cornell(orc, scenes):
