@@ -775,6 +775,10 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #define SRT_SVOTE_INNER_W 3
 #define SRT_SVOTE_LEAF_W 4
 #endif
+#ifndef SRT_SHADOW_MORE_STEPS
+#define SRT_SHADOW_MORE_STEPS 5  /* box steps a trip may add to its first one ... */
+#define SRT_SHADOW_MORE_MIN 16u  /* ... while at least this many lanes can take one */
+#endif
 #ifndef SRT_SHADOW_CHUNK_MAX
 #define SRT_SHADOW_CHUNK_MAX 1024u /* most shadow queries a wave draws from the shared counter at a time */
 #endif /* lights a block keeps in LDS; further ones are read from global memory */
@@ -1214,6 +1218,24 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                     swalk_inner_coarse<COUNT>(sc, w, stk, st);
                 else
                     swalk_inner<CULL, COUNT>(sc, w, stk, st);
+            }
+            /* Further box steps in the same trip while enough lanes stand on inner nodes: what a trip costs around its
+             * step (idle count, refill conditions, the two votes, the hand-in of answers) is paid once for up to
+             * six box steps (dragon shadow launch 138.8 -> 119.8 ms; 3 steps 121.5, 17 steps 123.0; thresholds 8 to 24
+             * lanes measure the same, 36 lose the gain). */
+            for (int rep = 0; rep < SRT_SHADOW_MORE_STEPS; ++rep) {
+                const bool again = atInner && w.alive && !(w.cur & SRT_LEAF_FLAG);
+                const unsigned long long mAgain = __ballot(again);
+                if ((uint32_t)__popcll(mAgain) < SRT_SHADOW_MORE_MIN)
+                    break;
+                if (COUNT && (int)lane == __ffsll((long long)mAgain) - 1)
+                    st.wave_inner += 1;
+                if (again) {
+                    if (COARSE)
+                        swalk_inner_coarse<COUNT>(sc, w, stk, st);
+                    else
+                        swalk_inner<CULL, COUNT>(sc, w, stk, st);
+                }
             }
         } else {
             if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
