@@ -56,6 +56,8 @@ def run(first, count):
     srt.set_device(0)
     bad = 0
     for seed in range(first, first + count):
+        if (seed - first) % 500 == 499:
+            print("...", seed - first + 1, "scenes,", bad, "mismatches", flush=True)  # a long run must keep writing
         rng = np.random.default_rng(seed)
         d, c = scene(rng)
         try:
