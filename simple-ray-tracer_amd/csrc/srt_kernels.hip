@@ -735,6 +735,121 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary(SceneDev sc, uint
     flush_counters(cnt, nPath, 0, 0, st);
 }
 
+/* k_trace_secondary with the shadow kernel's feeding: reflection rays differ in length as shadow queries do, so a lane
+ * whose query ends hands in its hit at once and, as soon as SRT_REFILL_MIN lanes of the wave are idle, the idle lanes take
+ * the wave's next rays, drawn in chunks from a counter all waves share (chunk size per launch as in k_trace_shadow).
+ * A ray outside the ranges of the fast slab test is walked to its end by its lane when it is taken. */
+template <bool CULL, bool COUNT>
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary_refill(SceneDev sc, uint32_t features, const float4* paths, const uint32_t* n_paths, HitQ hq,
+                                                                       uint32_t* hq_count, DevCounters* cnt, float* acc, unsigned long long* next_chunk)
+{
+    extern __shared__ uint2 lds_stack[];
+    uint2* stk = lds_stack + threadIdx.x;
+    Stats st = { 0, 0, 0, 0, 0 };
+    uint32_t nPath = 0;
+    const unsigned long long n = *n_paths;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long waves = (unsigned long long)gridDim.x * (SRT_BLOCK / 64);
+    uint32_t chunkItems = 64u;
+    {
+        const unsigned long long per = n / (waves * 16ull);
+        while (chunkItems < 1024u && 2ull * chunkItems <= per)
+            chunkItems *= 2u;
+        chunkItems = __builtin_amdgcn_readfirstlane(chunkItems);
+    }
+    const unsigned long long first_shared = waves * chunkItems;
+    auto uniform = [](unsigned long long v) {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    auto grab = [&]() {
+        unsigned long long base = 0;
+        if (lane == 0)
+            base = atomicAdd(next_chunk, (unsigned long long)chunkItems);
+        return first_shared + uniform(base);
+    };
+    unsigned long long chunk = uniform(((unsigned long long)blockIdx.x * (SRT_BLOCK / 64) + (threadIdx.x >> 6)) * chunkItems);
+    uint32_t used = 0;
+    bool dry = false;
+    Walk w;
+    w.alive = false;
+    w.o = mk3(0, 0, 0), w.d = mk3(0, 0, 1);
+    w.cur = 0, w.sp = 0, w.T = SRT_FLT_MAX, w.C = SRT_FLT_MAX, w.hitTri = 0xFFFFFFFFu;
+    w.rr.x = w.rr.y = w.rr.z = 0.0f;
+    uint32_t item = 0;
+    bool busy = false; /* the lane holds a ray: in flight (w.alive) or finished and waiting to be handed in */
+    for (;;) {
+        const unsigned long long spare = __ballot(!w.alive);
+        if (__popcll(spare) >= SRT_REFILL_MIN) {
+            /* hand in what has finished since the last time: one atomic for all of it */
+            const bool fin = busy && !w.alive;
+            const bool hit = fin && w.C != SRT_FLT_MAX;
+            if (fin && !hit && (features & SRT_F_ENVIRONMENT)) {
+                /* the environment seen by a reflected / transmitted ray, weighted like a hit's light (k_shade) */
+                const float4 b = paths[3ull * item + 1], c = paths[3ull * item + 2];
+                const f3 thr = mk3(b.z, b.w, c.x);
+                const f3 e = environment_color(sc, w.o, w.d, w.T);
+                float* a3 = acc + 3ull * __float_as_uint(c.y);
+                if (features & SRT_F_TRANSPARENCY) {
+                    atomicAdd(a3 + 0, thr.x * e.x);
+                    atomicAdd(a3 + 1, thr.y * e.y);
+                    atomicAdd(a3 + 2, thr.z * e.z);
+                } else {
+                    a3[0] = e.x, a3[1] = e.y, a3[2] = e.z;
+                }
+            }
+            const uint32_t q = queue_slot(hit, hq_count);
+            if (hit) {
+                hq.slot[q] = item;
+                hq.t[q] = w.T;
+                hq.tri[q] = w.hitTri;
+                const f3 ip = w.o + w.d * w.T;
+                hq.ip[q] = make_float4(ip.x, ip.y, ip.z, paths[3ull * item + 2].z);
+            }
+            busy = busy && w.alive;
+            if (!dry && used == chunkItems) {
+                chunk = grab();
+                used = 0;
+            }
+            dry = dry || chunk >= n;
+            if (!dry) {
+                const uint32_t cntSpare = (uint32_t)__popcll(spare);
+                const uint32_t pos = used + (uint32_t)__popcll(spare & ((1ull << lane) - 1ull));
+                unsigned long long mine = chunk + pos;
+                used += cntSpare;
+                if (used > chunkItems) {
+                    chunk = grab();
+                    used -= chunkItems;
+                    if (pos >= chunkItems)
+                        mine = chunk + (pos - chunkItems);
+                }
+                if (!busy && mine < n) {
+                    item = (uint32_t)mine;
+                    const float4 a = paths[3ull * item], b = paths[3ull * item + 1];
+                    const f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+                    nPath += 1;
+                    busy = true;
+                    if (ray_in_fast_range(sc, o, d)) {
+                        walk_begin<CULL, COUNT, true>(sc, w, o, d, SRT_FLT_MAX, st);
+                    } else {
+                        float T = SRT_FLT_MAX;
+                        uint32_t tri = 0xFFFFFFFFu;
+                        const bool h = traverse_loop<CULL, COUNT, false>(sc, o, d, T, tri, stk, st);
+                        w.o = o, w.d = d, w.T = T, w.hitTri = tri, w.C = h ? T : SRT_FLT_MAX;
+                        w.alive = false;
+                    }
+                }
+            }
+        }
+        if (!walk_trip<CULL, COUNT, true>(sc, w, stk, st)) {
+            /* nothing in flight: every lane is spare, so the next pass hands in and refills, or the wave is done */
+            if (dry && __ballot(busy) == 0)
+                break;
+        }
+    }
+    flush_counters(cnt, nPath, 0, 0, st);
+}
+
 /* Path ray and hit point data of queued hit h, as the shade kernel sees them. */
 SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4* cur_paths, uint32_t h, f3& o, f3& d, f3& thr, float& T,
                     uint32_t& tri, uint32_t& sample, uint32_t& path)
@@ -1611,7 +1726,7 @@ struct srt_device {
     int n_cu = 0;
     DevCounters* counters = nullptr; /* SRT_FAMILIES structs, one per kernel family, plus one for srt_intersect_batch */
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
-    unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
+    unsigned long long* chunk_counters = nullptr; /* 64: next unclaimed shadow item [0..31] and path ray [32..63] of each depth */
     DevBuf acc, chain, nlev, hq_slot, hq_t, hq_tri, hq_ip, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
     hipEvent_t ev[SRT_MAX_EVENTS];
     int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
@@ -1701,7 +1816,7 @@ int srt_device_create(int gpu_id, srt_device** out)
     if (e == hipSuccess)
         e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
     if (e == hipSuccess)
-        e = hipMalloc((void**)&d->chunk_counters, 32 * sizeof(unsigned long long));
+        e = hipMalloc((void**)&d->chunk_counters, 64 * sizeof(unsigned long long));
     if (e == hipSuccess)
         e = hipMemset(d->counters, 0, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e != hipSuccess) {
@@ -2016,7 +2131,7 @@ struct Work {
     unsigned char* vis = nullptr;    /* one byte per (hit, shadow query) */
     float4* path[2] = { nullptr, nullptr }; /* 3 float4 per queued path ray; only with reflections / transparency */
     uint32_t* qcounts = nullptr;     /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
-    unsigned long long* chunk_counters = nullptr; /* 32: next unclaimed shadow item of each depth */
+    unsigned long long* chunk_counters = nullptr; /* 64: next unclaimed shadow item [0..31] and path ray [32..63] of each depth */
     bool growable = false;           /* the queues may be enlarged between depths (transparency) */
 };
 
@@ -2043,7 +2158,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     float* acc = wk.acc;
     unsigned char* vis = wk.vis;
     HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 32 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 64 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
     const bool chained = (rp.features & SRT_F_RECURSIVE) && !(rp.features & SRT_F_TRANSPARENCY) && rp.max_depth > 0;
     float* chain = chained ? wk.chain : nullptr;
@@ -2110,6 +2225,16 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
             wk.path[depth & 1] = (float4*)d->path[depth & 1].p;
         }
         mark(d, st, 1, timing);
+        /* Rays fed like shadow queries (chunks + lane refill) once a rectangle is large: dragon stand-in 7680x4320, 64
+         * samples per pixel in 960x540 rectangles 223.6 -> 195.9 ms per frame (box steps at 45 instead of 34 lanes), but monkey
+         * 1920x1080, whose launches hold a few rays per lane, 0.674 -> 0.905 ms.  SRT_SECONDARY_REFILL=0 / 1 forces the choice
+         * (tests run both kernels at every size). */
+        static const char* refill_env = getenv("SRT_SECONDARY_REFILL");
+        const bool refill = refill_env ? refill_env[0] == '1' : rp.n_samples >= (1u << 24);
+        if (refill && (rp.features & SRT_F_ACCEL))
+            hipLaunchKernelGGL((k_trace_secondary_refill<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
+                path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc, wk.chunk_counters + 32 + depth);
+        else
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
             path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc);
     }
@@ -2355,7 +2480,7 @@ int srt_render_noalloc(srt_device* d, srt_scene* sc, const srt_render_params* p,
     };
     Work wk;
     wk.qcounts = (uint32_t*)carve(64 * sizeof(uint32_t));
-    wk.chunk_counters = (unsigned long long*)carve(32 * sizeof(unsigned long long));
+    wk.chunk_counters = (unsigned long long*)carve(64 * sizeof(unsigned long long));
     wk.acc = (float*)carve((size_t)n * 12);
     wk.hq.slot = (uint32_t*)carve((size_t)n * 4);
     wk.hq.t = (float*)carve((size_t)n * 4);
