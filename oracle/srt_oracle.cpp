@@ -25,6 +25,7 @@
 #include <array>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifdef _OPENMP
@@ -102,6 +103,8 @@ struct orc_bvh {
     bool coarse_ok = false;
     float q_scale[3] = { 1.0f, 1.0f, 1.0f };
     std::vector<std::array<uint32_t, 3>> cq; /* per node: its box on the 16-bit grid, lower | upper << 16 per axis */
+    std::vector<std::array<uint32_t, 3>> tq; /* per entry of order[]: that triangle's own box on the grid */
+    size_t wide_cap = 0; /* pending siblings a coarse shadow walk may stack; a query that wants more takes the exact walk */
 };
 
 namespace {
@@ -473,9 +476,12 @@ bool intersect(Ctx& c, Ray& ray, HitInfo& hit)
 
 /* ---------------------------------------------------------------- shadow queries on coarse boxes
  * The policy ORC_F_COARSE_SHADOW of the HIP path, restated (it has no counterpart in the reference: like
- * ORC_F_MISS_CULL it only changes which boxes a query looks into).  A shadow query tests the children of an inner node
- * on a 16-bit grid over the root box, each box rounded outwards by more than a grid step, with one fused
- * multiply-add per slab value; the first leaf with an accepted triangle answers it when the hit lies below 0.99 and
+ * ORC_F_MISS_CULL it only changes which boxes a query looks into).  A shadow query tests boxes on a 16-bit grid over
+ * the root box, each rounded outwards by more than a grid step, with one fused multiply-add per slab value, and two
+ * levels at a time: at an inner node of even level it tests the four grandchildren (a child that is a leaf stands for
+ * itself) in the order the reference's walk would pop them - right-right, right-left, left-right, left-left - goes on
+ * in the first one the ray meets and stacks the others.  The first leaf with an accepted triangle answers the query
+ * when the hit lies below 0.99 and
  * hands it to the exact walk otherwise.  Every float operation is written out in the order the kernels use. */
 inline bool fast_dir(float d)
 {
@@ -524,7 +530,26 @@ void coarse_prepare(orc_bvh& b)
                 b.cq[i][k] = coarse_axis(lo[k], hi[k], rlo[k], b.q_scale[k], bad);
         }
     }
+    /* boxes of single triangles, for the records whose leaves are listed triangle by triangle */
+    b.tq.assign(b.order.size(), { 0u, 0u, 0u });
+    for (size_t i = 0; i < b.order.size(); ++i) {
+        const orc_scene& s = b.s;
+        const uint32_t* t = s.tris + 3ull * (s.mesh_tri_off[b.order[i].mesh] + b.order[i].tri);
+        const float* base = s.verts + 8ull * s.mesh_vert_off[b.order[i].mesh];
+        const float *p0 = base + 8ull * t[0], *p1 = base + 8ull * t[1], *p2 = base + 8ull * t[2];
+        for (int k = 0; k < 3; ++k) {
+            const float lo = fmin_std(fmin_std(p0[k], p1[k]), p2[k]), hi = fmax_std(fmax_std(p0[k], p1[k]), p2[k]);
+            b.tq[i][k] = coarse_axis(lo, hi, rlo[k], b.q_scale[k], bad);
+        }
+    }
     b.coarse_ok = !bad;
+    /* the HIP path's stack capacity for this walk: levels + 1; SRT_WIDE_CAP lowers it on both sides (tests) */
+    b.wide_cap = (size_t)b.levels + 1;
+    if (const char* cap = std::getenv("SRT_WIDE_CAP")) {
+        const long v = std::strtol(cap, nullptr, 10);
+        if (v >= 0 && (size_t)v < b.wide_cap)
+            b.wide_cap = (size_t)v;
+    }
 }
 struct CoarseRay {
     float qi[3], qc[3];
@@ -565,17 +590,19 @@ bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
         if (!(og >= -65536.0f && og <= 131072.0f))
             return false;
     }
+    /* a walk position: a node (>= 0), or a single triangle given by its place in order[] (-(place + 1)) */
     std::vector<int> stack;
     int cur = (int)bvh.nodes.size() - 1;
     for (;;) {
-        const Node& n = bvh.nodes[cur];
         bool descended = false;
-        if (n.leaf) {
+        c.cnt.node_visits += 1;
+        if (cur < 0 || bvh.nodes[cur].leaf) {
+            const int first = cur < 0 ? -(cur + 1) : bvh.nodes[cur].a, count = cur < 0 ? 1 : bvh.nodes[cur].b;
             Ray r = ray;
             HitInfo h = like;
             bool hit = false;
-            for (int k = 0; k < n.b; ++k) {
-                TriRef t = bvh.order[n.a + k];
+            for (int k = 0; k < count; ++k) {
+                TriRef t = bvh.order[first + k];
                 if (leaf_triangle(c, r, h, t.mesh, t.tri))
                     hit = true;
             }
@@ -587,16 +614,61 @@ bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
                 return false;
             }
         } else {
-            const bool pushL = coarse_meets(bvh.cq[n.a], cr), pushR = coarse_meets(bvh.cq[n.b], cr);
-            if (pushL && pushR) {
-                stack.push_back(n.a);
-                cur = n.b;
-                descended = true;
-            } else if (pushR) {
-                cur = n.b;
-                descended = true;
-            } else if (pushL) {
-                cur = n.a;
+            const Node& n = bvh.nodes[cur];
+            c.cnt.inner_visits += 1;
+            c.cnt.box_tests += 4;
+            int slot[4], ns = 0;
+            for (int child : { n.b, n.a }) {
+                const Node& cn = bvh.nodes[child];
+                if (cn.leaf) {
+                    slot[ns++] = child;
+                } else {
+                    slot[ns++] = cn.b;
+                    slot[ns++] = cn.a;
+                }
+            }
+            /* leaves listed triangle by triangle when that fits the four slots */
+            int singles = 0;
+            bool anyLeaf = false;
+            for (int k = 0; k < ns; ++k) {
+                const Node& sn = bvh.nodes[slot[k]];
+                anyLeaf = anyLeaf || sn.leaf;
+                singles += sn.leaf ? sn.b : 1;
+            }
+            if (anyLeaf && singles <= 4) {
+                int wide[4], nw = 0;
+                for (int k = 0; k < ns; ++k) {
+                    const Node& sn = bvh.nodes[slot[k]];
+                    if (sn.leaf && sn.b != 1) {
+                        for (int j = 0; j < sn.b; ++j)
+                            wide[nw++] = -(sn.a + j + 1);
+                    } else {
+                        wide[nw++] = slot[k];
+                    }
+                }
+                ns = nw;
+                for (int k = 0; k < ns; ++k)
+                    slot[k] = wide[k];
+            }
+            bool met[4];
+            int first = -1;
+            size_t pushes = 0;
+            for (int k = 0; k < ns; ++k) {
+                met[k] = coarse_meets(slot[k] < 0 ? bvh.tq[-(slot[k] + 1)] : bvh.cq[slot[k]], cr);
+                if (met[k]) {
+                    if (first < 0)
+                        first = k;
+                    else
+                        pushes += 1;
+                }
+            }
+            if (stack.size() + pushes > bvh.wide_cap)
+                return false; /* the HIP path's stack would not hold them: the exact walk answers */
+            for (int k = ns - 1; k > first && first >= 0; --k)
+                if (met[k])
+                    stack.push_back(slot[k]);
+            if (first >= 0) {
+                cur = slot[first];
                 descended = true;
             }
         }

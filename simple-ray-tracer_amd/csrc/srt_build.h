@@ -411,6 +411,9 @@ int srt_scene_build(srt_device* dev, const srt_build_desc* desc, srt_scene** out
     }
     fast = fast && root_box[0] <= root_box[3] && root_box[1] <= root_box[4] && root_box[2] <= root_box[5];
     v.fast_boxes = fast ? 1u : 0u;
+    s->host_children.resize(2 * shape.size());
+    for (size_t i = 0; i < shape.size(); ++i)
+        s->host_children[2 * i] = shape[i].left, s->host_children[2 * i + 1] = shape[i].right;
     rc = scene_grids(dev, s);
     lap("frees and launch shapes");
     if (rc != SRT_OK) {

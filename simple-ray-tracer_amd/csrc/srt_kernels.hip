@@ -67,11 +67,16 @@ struct SceneDev {
     int32_t env_tex;     /* texture index of the environment image, -1 for none */
     uint32_t fast_boxes; /* every box has lower <= upper and coordinates 0 or 2^-40 <= |c| < 2^20: slab_test_fast applies */
     uint64_t n_texels;
-    /* coarse copy of the node array for shadow queries (k_coarsen): per node two uint4, one per child: the child's box
-     * on a 16-bit grid over the root box, rounded outwards (x: lower | upper << 16, y, z), and the child reference */
-    const uint4* cnodes;
+    /* four-wide coarse nodes for shadow queries (k_widen): one record of four uint4 per inner node of even depth, one
+     * uint4 per slot: the box of a grandchild (or of a child that is a leaf) on a 16-bit grid over the root box, rounded
+     * outwards (x: lower | upper << 16, y, z), and its reference (leaf reference, or index into this array); slots in
+     * the order the reference's walk pops them, unused ones (SRT_WIDE_EMPTY) last */
+    const uint4* wnodes;
     float q_scale[3];          /* grid coordinate of x: (x - root_lo) * q_scale + 1 */
-    uint32_t coarse_ok;        /* cnodes is usable: every child box lies inside the root box */
+    uint32_t wide_cap;         /* pending siblings a shadow query may stack on the wide nodes; beyond: the exact walk */
+    uint32_t n_wide;           /* records in wnodes */
+    uint32_t n_top;            /* the first n_top records are the top levels of the tree: the shadow kernel keeps them in LDS */
+    uint32_t coarse_ok;        /* wnodes is usable: every child box lies inside the root box */
 };
 
 struct DevCounters {
@@ -884,6 +889,9 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #define SRT_SHADOW_BLOCK 256
 #endif
 #define SRT_LDS_LIGHTS 16u
+#ifndef SRT_WIDE_LDS_NODES
+#define SRT_WIDE_LDS_NODES 21u /* wide records (64 bytes each) of the tree's top levels a block of the shadow kernel keeps in LDS */
+#endif
 #ifndef SRT_SVOTE_INNER_W
 /* Vote weights of the shadow walk, box step : leaf step (dragon / teapot shadow launch: 1:2 141.4 / 0.752 ms, 3:4 138.7 /
  * 0.746, 1:1 139.2 / 0.759, 4:3 141.6 / 0.767) */
@@ -1029,15 +1037,26 @@ SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
     }
 }
 
-/* ---- coarse boxes for shadow queries.
+/* ---- coarse, four-wide nodes for shadow queries.
  * Before its first hit a shadow query asks of a box only whether the ray meets it.  Any box that contains the
  * child's box answers that question safely (a superset of the nodes is visited, the triangle tests decide), so the
- * shadow walk reads a coarse copy of the node array: child boxes on a 16-bit grid over the root box, rounded outwards
- * by more than a grid step - 32 bytes per node instead of 64, two 16-byte loads per visit instead of four, and the
- * slab values by one fused multiply-add per coordinate in grid space, without the exact division the closest-hit
- * walks need.  The margin of one grid step on either side covers the rounding of everything involved: the grid
- * coordinate of a bound or of the origin is off by less than 0.02 steps, a slab value by less than 0.03 steps of
- * travel along its axis for an origin within one root-box size of the root box (other rays take the exact walk). */
+ * shadow walk reads boxes on a 16-bit grid over the root box, rounded outwards by more than a grid step: 12 bytes per
+ * box instead of 24, and the slab values by one fused multiply-add per coordinate in grid space, without the exact
+ * division the closest-hit walks need.  The margin of one grid step on either side covers the rounding of everything
+ * involved: the grid coordinate of a bound or of the origin is off by less than 0.02 steps, a slab value by less
+ * than 0.03 steps of travel along its axis for an origin within one root-box size of the root box (other rays take
+ * the exact walk).
+ * Two levels of the tree are folded into one record.  A child's box lies inside its parent's, outward rounding and
+ * the grid-space slab values are monotone, so a ray that meets a grandchild's coarse box meets the coarse box of the
+ * child in between: testing the four grandchildren directly visits exactly the leaves the level-by-level walk on the
+ * same grid visits.  The reference's walk pops the right child before the left one (src/bounding_volume_hierarchy.cpp:
+ * 370-385), so the grandchildren are met in the order right-right, right-left, left-right, left-left; the record
+ * lists them in that order (a child that is a leaf takes one slot), the walk goes on in the first one the ray meets
+ * and stacks the others, last one first.  A query therefore takes half the dependent node visits, for the same 64
+ * bytes per two levels and never more box tests. */
+#define SRT_WIDE_EMPTY 0xFFFFFFFFu /* no leaf reference has this value: first + count would pass 2^24 triangles */
+#define SRT_WIDE_NONE 0xFFFFFFFFu  /* wide_of[] of an inner node of odd depth */
+
 SRT_DI uint32_t coarse_axis(float lo, float hi, float rlo, float s, bool& bad)
 {
     const float ul = (lo - rlo) * s, uh = (hi - rlo) * s;
@@ -1048,20 +1067,85 @@ SRT_DI uint32_t coarse_axis(float lo, float hi, float rlo, float s, bool& bad)
     return (uint32_t)ql | ((uint32_t)qh << 16);
 }
 
-__global__ __launch_bounds__(SRT_BLOCK) void k_coarsen(const float4* __restrict__ nodes, uint32_t n, float lox, float loy, float loz, float sx, float sy,
-                                                         float sz, uint4* __restrict__ out, uint32_t* bad_flag)
+struct GridMap {
+    float lo[3], scale[3];
+};
+
+SRT_DI uint4 coarse_slot(f3 lo, f3 hi, uint32_t ref, const GridMap& g, bool& bad)
+{
+    uint4 s;
+    s.x = coarse_axis(lo.x, hi.x, g.lo[0], g.scale[0], bad);
+    s.y = coarse_axis(lo.y, hi.y, g.lo[1], g.scale[1], bad);
+    s.z = coarse_axis(lo.z, hi.z, g.lo[2], g.scale[2], bad);
+    s.w = ref;
+    return s;
+}
+
+/* One thread per inner node; those of even depth (wide_of[i] is their position in the wide array) write a record.
+ * When the triangles of the record's leaves fit the four slots one by one, every triangle gets a slot of its own, with
+ * its own box, in the order the leaves hold them (the reference tests a leaf's triangles in stored order,
+ * src/bounding_volume_hierarchy.cpp:359-368): the bottom records of a depth-capped tree then cull single triangles
+ * before any triangle record is read. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_widen(const float4* __restrict__ nodes, uint32_t n, const uint32_t* __restrict__ wide_of,
+                                                       const float4* __restrict__ tris, GridMap g, uint4* __restrict__ out, uint32_t* bad_flag)
 {
     const uint32_t i = blockIdx.x * SRT_BLOCK + threadIdx.x;
     if (i >= n)
         return;
-    const float4 a = nodes[4ull * i], b = nodes[4ull * i + 1], c = nodes[4ull * i + 2], e = nodes[4ull * i + 3];
+    const uint32_t wid = wide_of[i];
+    if (wid == SRT_WIDE_NONE)
+        return;
     bool bad = false;
-    uint4 L, R;
-    L.x = coarse_axis(a.x, a.w, lox, sx, bad), L.y = coarse_axis(a.y, b.x, loy, sy, bad), L.z = coarse_axis(a.z, b.y, loz, sz, bad);
-    L.w = __float_as_uint(e.x);
-    R.x = coarse_axis(b.z, c.y, lox, sx, bad), R.y = coarse_axis(b.w, c.z, loy, sy, bad), R.z = coarse_axis(c.x, c.w, loz, sz, bad);
-    R.w = __float_as_uint(e.y);
-    out[2ull * i] = L, out[2ull * i + 1] = R;
+    f3 lo[4], hi[4];
+    uint32_t ref[4];
+    int used = 0;
+    const float4 a = nodes[4ull * i], b = nodes[4ull * i + 1], c = nodes[4ull * i + 2], e = nodes[4ull * i + 3];
+    /* right child first: the order the reference pops them in */
+    const f3 clo[2] = { mk3(b.z, b.w, c.x), mk3(a.x, a.y, a.z) }, chi[2] = { mk3(c.y, c.z, c.w), mk3(a.w, b.x, b.y) };
+    const uint32_t cref[2] = { __float_as_uint(e.y), __float_as_uint(e.x) };
+    for (int side = 0; side < 2; ++side) {
+        if (cref[side] & SRT_LEAF_FLAG) {
+            lo[used] = clo[side], hi[used] = chi[side], ref[used] = cref[side];
+            used += 1;
+            continue;
+        }
+        const float4* cn = nodes + 4ull * cref[side];
+        const float4 p = cn[0], q = cn[1], r = cn[2], t = cn[3];
+        const uint32_t gr = __float_as_uint(t.y), gl = __float_as_uint(t.x);
+        lo[used] = mk3(q.z, q.w, r.x), hi[used] = mk3(r.y, r.z, r.w), ref[used] = (gr & SRT_LEAF_FLAG) ? gr : wide_of[gr];
+        used += 1;
+        lo[used] = mk3(p.x, p.y, p.z), hi[used] = mk3(p.w, q.x, q.y), ref[used] = (gl & SRT_LEAF_FLAG) ? gl : wide_of[gl];
+        used += 1;
+    }
+    uint32_t singles = 0;
+    bool anyLeaf = false;
+    for (int k = 0; k < used; ++k) {
+        const bool leaf = (ref[k] & SRT_LEAF_FLAG) != 0;
+        anyLeaf = anyLeaf || leaf;
+        singles += leaf ? ((ref[k] >> 24) & 0x7Fu) : 1u;
+    }
+    uint4 slot[4];
+    for (int k = 0; k < 4; ++k)
+        slot[k] = make_uint4(0u, 0u, 0u, SRT_WIDE_EMPTY);
+    int w = 0;
+    for (int k = 0; k < used; ++k) {
+        const uint32_t cnt = (ref[k] >> 24) & 0x7Fu;
+        if (anyLeaf && singles <= 4u && (ref[k] & SRT_LEAF_FLAG) && cnt != 1u) {
+            /* one slot per triangle (an empty leaf leaves none) */
+            const uint32_t first = ref[k] & 0x00FFFFFFu;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const float4* rec = tris + 6ull * (first + j);
+                const f3 v0 = xyz(rec[1]), v1 = xyz(rec[2]), v2 = xyz(rec[3]);
+                const f3 tlo = mk3(min_std(min_std(v0.x, v1.x), v2.x), min_std(min_std(v0.y, v1.y), v2.y), min_std(min_std(v0.z, v1.z), v2.z));
+                const f3 thi = mk3(max_std(max_std(v0.x, v1.x), v2.x), max_std(max_std(v0.y, v1.y), v2.y), max_std(max_std(v0.z, v1.z), v2.z));
+                slot[w++] = coarse_slot(tlo, thi, SRT_LEAF_FLAG | (1u << 24) | (first + j), g, bad);
+            }
+        } else {
+            slot[w++] = coarse_slot(lo[k], hi[k], ref[k], g, bad);
+        }
+    }
+    for (int k = 0; k < 4; ++k)
+        out[4ull * wid + k] = slot[k];
     if (bad)
         atomicOr(bad_flag, 1u);
 }
@@ -1086,28 +1170,51 @@ SRT_DI bool coarse_meets(const uint4& b, const Walk& w)
     return !(tin > tout || tout < 0.0f || tin > 1.0f);
 }
 
-/* swalk_inner on the coarse node array (miss culling only: without it no box is tested at all). */
+/* Visit of the wide node the lane stands on (miss culling only: without it no box is tested at all): the walk goes on
+ * in the first slot the ray meets and stacks the other met ones, last first, so that they come off the stack in slot
+ * order.  Returns true, with the walk stopped, when the stack would outgrow `cap` entries: the caller then answers the
+ * query with the exact walk. */
 template <bool COUNT>
-SRT_DI void swalk_inner_coarse(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
+SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint32_t* stk, Stats& st)
 {
     if (COUNT) {
         st.inner += 1;
-        st.box += 2;
+        st.box += 4;
     }
-    const uint4* nd = sc.cnodes + 2ull * w.cur;
-    const uint4 L = nd[0], R = nd[1];
-    const bool pushL = coarse_meets(L, w), pushR = coarse_meets(R, w);
-    if (pushL && pushR) {
-        stk[w.sp * SRT_SHADOW_BLOCK] = L.w;
-        ++w.sp;
-        w.cur = R.w;
-    } else if (pushR) {
-        w.cur = R.w;
-    } else if (pushL) {
-        w.cur = L.w;
+    uint4 s0, s1, s2, s3;
+    if (w.cur < sc.n_top) {
+        const uint4* nd = top + 4u * w.cur; /* the block's LDS copy of the top levels */
+        s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     } else {
-        w.alive = swalk_pop(w, stk);
+        const uint4* nd = sc.wnodes + 4ull * w.cur;
+        s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     }
+    /* `&`, not `&&`: all four slots are tested without branches, so the record's four quarters are requested together */
+    const bool m0 = (s0.w != SRT_WIDE_EMPTY) & coarse_meets(s0, w), m1 = (s1.w != SRT_WIDE_EMPTY) & coarse_meets(s1, w);
+    const bool m2 = (s2.w != SRT_WIDE_EMPTY) & coarse_meets(s2, w), m3 = (s3.w != SRT_WIDE_EMPTY) & coarse_meets(s3, w);
+    const bool p1 = m1 & m0, p2 = m2 & (m0 | m1), p3 = m3 & (m0 | m1 | m2);
+    const int pushes = (int)p1 + (int)p2 + (int)p3;
+    if (w.sp + pushes > (int)sc.wide_cap) {
+        w.alive = false;
+        return true;
+    }
+    if (p3) {
+        stk[w.sp * SRT_SHADOW_BLOCK] = s3.w;
+        ++w.sp;
+    }
+    if (p2) {
+        stk[w.sp * SRT_SHADOW_BLOCK] = s2.w;
+        ++w.sp;
+    }
+    if (p1) {
+        stk[w.sp * SRT_SHADOW_BLOCK] = s1.w;
+        ++w.sp;
+    }
+    if (m0 || m1 || m2 || m3)
+        w.cur = m0 ? s0.w : (m1 ? s1.w : (m2 ? s2.w : s3.w));
+    else
+        w.alive = swalk_pop(w, stk);
+    return false;
 }
 
 /* Leaf visit of the common shadow walk.  Returns 0: no hit, walk on; 1: occluded; 2: first hit in [0.99, 1]. */
@@ -1180,15 +1287,19 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                                                               const float4* cur_paths, unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt,
                                                               unsigned long long* next_chunk)
 {
-    /* LDS: the first lights of the scene (a refill reads its light from here instead of global memory), then the
-     * per-lane stacks */
+    /* LDS: the first lights of the scene (a refill reads its light from here instead of global memory), the wide
+     * records of the tree's top levels, then the per-lane stacks */
     extern __shared__ uint32_t lds_shadow[];
     const srt_light* lds_lights = (const srt_light*)lds_shadow;
     const uint32_t nLdsLights = sc.n_lights < SRT_LDS_LIGHTS ? sc.n_lights : SRT_LDS_LIGHTS;
     for (uint32_t i = threadIdx.x; i < nLdsLights * (uint32_t)(sizeof(srt_light) / 4); i += SRT_SHADOW_BLOCK)
         lds_shadow[i] = ((const uint32_t*)sc.lights)[i];
+    uint4* lds_top = (uint4*)(lds_shadow + SRT_LDS_LIGHTS * (uint32_t)(sizeof(srt_light) / 4));
+    const uint32_t nTop = COARSE ? sc.n_top : 0u;
+    for (uint32_t i = threadIdx.x; i < nTop * 4u; i += SRT_SHADOW_BLOCK)
+        lds_top[i] = sc.wnodes[i];
     __syncthreads();
-    uint32_t* stk = lds_shadow + SRT_LDS_LIGHTS * (uint32_t)(sizeof(srt_light) / 4) + threadIdx.x;
+    uint32_t* stk = lds_shadow + SRT_LDS_LIGHTS * (uint32_t)(sizeof(srt_light) / 4) + SRT_WIDE_LDS_NODES * 16u + threadIdx.x;
     Stats st = { 0, 0, 0, 0, 0 };
     uint32_t nShadow = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1329,10 +1440,12 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             if (COUNT && (int)lane == __ffsll((long long)mInner) - 1)
                 st.wave_inner += 1;
             if (atInner) {
-                if (COARSE)
-                    swalk_inner_coarse<COUNT>(sc, w, stk, st);
-                else
+                if (COARSE) {
+                    if (swalk_inner_wide<COUNT>(sc, lds_top, w, stk, st))
+                        verdict = 2; /* more pending siblings than the stack holds */
+                } else {
                     swalk_inner<CULL, COUNT>(sc, w, stk, st);
+                }
             }
             /* Further box steps in the same trip while enough lanes stand on inner nodes: what a trip costs around its
              * step (idle count, refill conditions, the two votes, the hand-in of answers) is paid once for up to
@@ -1346,10 +1459,12 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                 if (COUNT && (int)lane == __ffsll((long long)mAgain) - 1)
                     st.wave_inner += 1;
                 if (again) {
-                    if (COARSE)
-                        swalk_inner_coarse<COUNT>(sc, w, stk, st);
-                    else
+                    if (COARSE) {
+                        if (swalk_inner_wide<COUNT>(sc, lds_top, w, stk, st))
+                            verdict = 2;
+                    } else {
                         swalk_inner<CULL, COUNT>(sc, w, stk, st);
+                    }
                 }
             }
         } else {
@@ -1746,6 +1861,7 @@ struct srt_scene {
     uint32_t num_leaves = 0;
     Grids grids[2][2]; /* [miss culling][counting kernels]; fixed at upload: they depend on the stack depth only */
     std::vector<uint32_t> light_types; /* host copy: sizes the shadow-query stage */
+    std::vector<uint32_t> host_children; /* (left, right) of every inner node, from upload / build until scene_coarsen has used it */
     std::vector<void*> allocs;
 };
 
@@ -1957,6 +2073,7 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
      * order gives every inner node's depth: the per-lane stacks hold one pending sibling per inner level and
      * are sized from num_levels, which therefore must cover the deepest leaf (inner depth + 2 levels). */
     std::vector<uint32_t> depth(desc->n_nodes, 0);
+    std::vector<uint8_t> referenced(desc->n_nodes, 0);
     uint32_t deepest = 0;
     for (uint32_t i = 0; i < desc->n_nodes && rc == SRT_OK; ++i) {
         rc = check_ref(desc, desc->nodes[i].left, "left child");
@@ -1965,10 +2082,15 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         for (uint32_t child : { desc->nodes[i].left, desc->nodes[i].right }) {
             if (rc != SRT_OK || (child & SRT_LEAF_FLAG))
                 continue;
-            if (child <= i)
+            if (child <= i) {
                 rc = fail(SRT_ERR_INVALID, "node %u: child index %u does not follow its parent", i, child);
-            else
+            } else if (referenced[child]) {
+                /* a node with two parents could sit deeper than the pass below records, and the stacks are sized by depth */
+                rc = fail(SRT_ERR_INVALID, "node %u is the child of more than one node", child);
+            } else {
+                referenced[child] = 1;
                 depth[child] = depth[i] + 1;
+            }
         }
         if (depth[i] > deepest)
             deepest = depth[i];
@@ -2050,6 +2172,9 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
     for (uint32_t i = 0; i < desc->n_nodes && fast; ++i)
         fast = box_ok(desc->nodes[i].lbox) && box_ok(desc->nodes[i].rbox);
     v.fast_boxes = fast ? 1u : 0u;
+    s->host_children.resize(2ull * desc->n_nodes);
+    for (uint32_t i = 0; i < desc->n_nodes; ++i)
+        s->host_children[2ull * i] = desc->nodes[i].left, s->host_children[2ull * i + 1] = desc->nodes[i].right;
     rc = scene_grids(dev, s);
     if (rc != SRT_OK) {
         srt_scene_destroy(s);
@@ -2075,7 +2200,7 @@ void srt_scene_destroy(srt_scene* s)
 /* Stack capacity: at most one pending left sibling per inner level. */
 static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + SRT_STACK_SLACK; }
 static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
-static size_t shadow_lds_bytes(const srt_scene* s) { return SRT_LDS_LIGHTS * sizeof(srt_light) + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
+static size_t shadow_lds_bytes(const srt_scene* s) { return SRT_LDS_LIGHTS * sizeof(srt_light) + SRT_WIDE_LDS_NODES * 64u + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
 
 template <typename K>
 static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid, int block = SRT_BLOCK)
@@ -2260,34 +2385,90 @@ static int fill_grids(srt_device* d, srt_scene* sc)
     return rc;
 }
 
-/* The coarse node array of a freshly uploaded or built scene (see coarse_axis). */
+/* The wide coarse nodes of a freshly uploaded or built scene (see k_widen).  s->host_children holds the child
+ * references of every inner node (left, right), as validated by the caller: an inner child's index is larger than its
+ * parent's, so one pass in index order gives every node's depth. */
 static int scene_coarsen(srt_scene* s)
 {
     SceneDev& v = s->view;
-    v.cnodes = nullptr, v.coarse_ok = 0;
+    v.wnodes = nullptr, v.coarse_ok = 0, v.wide_cap = 0, v.n_wide = 0, v.n_top = 0;
+    GridMap g;
     for (int k = 0; k < 3; ++k) {
         const float ext = v.root_hi[k] - v.root_lo[k];
         v.q_scale[k] = ext > 0.0f ? 65533.0f / ext : 1.0f;
+        g.lo[k] = v.root_lo[k], g.scale[k] = v.q_scale[k];
     }
+    std::vector<uint32_t> children;
+    children.swap(s->host_children);
     if (!v.n_nodes || !v.fast_boxes)
         return SRT_OK;
-    void *p = nullptr, *flag = nullptr;
-    HIPCHK(hipMalloc(&p, (size_t)v.n_nodes * 32));
+    if (children.size() != 2ull * v.n_nodes)
+        return fail(SRT_ERR_INVALID, "internal: child references of %u nodes expected, %zu given", v.n_nodes, children.size() / 2);
+    std::vector<uint32_t> depth(v.n_nodes, 0), wide_of(v.n_nodes, SRT_WIDE_NONE);
+    uint32_t deepest = 0;
+    std::vector<uint32_t> per_depth;
+    for (uint32_t i = 0; i < v.n_nodes; ++i) {
+        if (depth[i] > deepest)
+            deepest = depth[i];
+        if (!(depth[i] & 1u)) {
+            if (per_depth.size() <= depth[i] / 2)
+                per_depth.resize(depth[i] / 2 + 1, 0);
+            per_depth[depth[i] / 2] += 1;
+        }
+        for (int k = 0; k < 2; ++k) {
+            const uint32_t c = children[2ull * i + k];
+            if (!(c & SRT_LEAF_FLAG))
+                depth[c] = depth[i] + 1;
+        }
+    }
+    /* Numbering of the wide array: first the records of the tree's top levels, as many whole levels as the shadow
+     * kernel's LDS area holds (every query starts there, and gathers from LDS do not queue at the vector memory
+     * path), then all others in index order - depth first, right child first, like the node array. */
+    uint32_t top_levels = 0, n_top = 0;
+    while (top_levels < per_depth.size() && n_top + per_depth[top_levels] <= SRT_WIDE_LDS_NODES)
+        n_top += per_depth[top_levels++];
+    uint32_t next_top = 0, next_rest = n_top;
+    for (uint32_t i = 0; i < v.n_nodes; ++i)
+        if (!(depth[i] & 1u))
+            wide_of[i] = depth[i] / 2 < top_levels ? next_top++ : next_rest++;
+    const uint32_t n_wide = next_rest;
+    /* Stack capacity of the wide walk: the tree's levels + 1 (deepest inner node + its leaves + 1), which the LDS
+     * stacks (num_levels + SRT_STACK_SLACK entries) always hold.  A wide node can leave three siblings pending, so a
+     * query can in principle want up to 1.5 entries per level; one that does is answered by the exact walk.
+     * SRT_WIDE_CAP lowers the capacity (tests of that path). */
+    v.wide_cap = deepest + 3;
+    if (v.wide_cap > s->num_levels + SRT_STACK_SLACK)
+        v.wide_cap = s->num_levels + SRT_STACK_SLACK;
+    if (const char* cap = getenv("SRT_WIDE_CAP")) {
+        const long c = strtol(cap, nullptr, 10);
+        if (c >= 0 && (uint32_t)c < v.wide_cap)
+            v.wide_cap = (uint32_t)c;
+    }
+    void *p = nullptr, *map = nullptr, *flag = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t)n_wide * 64));
     s->allocs.push_back(p);
-    HIPCHK(hipMalloc(&flag, 4));
+    HIPCHK(hipMalloc(&map, (size_t)v.n_nodes * 4));
+    hipError_t e = hipMalloc(&flag, 4);
     uint32_t bad = 0;
-    hipError_t e = hipMemset(flag, 0, 4);
+    if (e == hipSuccess)
+        e = hipMemcpy(map, wide_of.data(), (size_t)v.n_nodes * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemset(flag, 0, 4);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_coarsen, dim3((v.n_nodes + SRT_BLOCK - 1) / SRT_BLOCK), dim3(SRT_BLOCK), 0, 0, v.nodes, v.n_nodes, v.root_lo[0], v.root_lo[1], v.root_lo[2],
-            v.q_scale[0], v.q_scale[1], v.q_scale[2], (uint4*)p, (uint32_t*)flag);
+        hipLaunchKernelGGL(k_widen, dim3((v.n_nodes + SRT_BLOCK - 1) / SRT_BLOCK), dim3(SRT_BLOCK), 0, 0, v.nodes, v.n_nodes, (const uint32_t*)map, v.tris, g, (uint4*)p,
+            (uint32_t*)flag);
         e = hipGetLastError();
     }
     if (e == hipSuccess)
         e = hipMemcpy(&bad, flag, 4, hipMemcpyDeviceToHost);
-    (void)hipFree(flag);
+    (void)hipFree(map);
+    if (flag)
+        (void)hipFree(flag);
     if (e != hipSuccess)
-        return fail(SRT_ERR_HIP, "coarse node array: %s", hipGetErrorString(e));
-    v.cnodes = (const uint4*)p;
+        return fail(SRT_ERR_HIP, "wide node array: %s", hipGetErrorString(e));
+    v.wnodes = (const uint4*)p;
+    v.n_wide = n_wide;
+    v.n_top = n_top;
     v.coarse_ok = bad ? 0u : 1u;
     return SRT_OK;
 }

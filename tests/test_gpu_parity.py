@@ -342,9 +342,10 @@ def test_many_lights(orc, pair):
 
 @pytest.mark.parametrize("name,res", [("cornell_parallelogram", (96, 96)), ("monkey", (128, 96)), ("teapot", (96, 54)), ("cube", (80, 60))])
 def test_coarse_shadow_boxes(orc, pair, name, res):
-    """Shadow queries on the half-size node array (16-bit outward-rounded child boxes): the frame with soft and hard
-    shadows and reflections equals the oracle's under the same policy, and equals the frame on full-precision boxes
-    bit for bit - a coarse box can only add nodes to a query's walk, the triangle tests decide."""
+    """Shadow queries on the four-wide coarse nodes (16-bit outward-rounded boxes of the grandchildren): the frame with
+    soft and hard shadows and reflections equals the oracle's under the same policy - node visits and triangle tests
+    included, the oracle restates the walk - and equals the frame on full-precision boxes bit for bit: a coarse box can
+    only add nodes to a query's walk, the triangle tests decide."""
     ob, gb = pair(name)
     base = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_RECURSIVE | srt.F_MISS_CULL
     want = ob.render(orc.make_camera(*res), base | srt.F_COARSE_SHADOW)
@@ -352,10 +353,36 @@ def test_coarse_shadow_boxes(orc, pair, name, res):
     exact = gb.render(srt.make_camera(*res), base, flags=srt.RENDER_STATS)
     _compare_frames(got, want, f"{name}/coarse shadow boxes")
     assert np.array_equal(got["rgb"].view(np.uint32), exact["rgb"].view(np.uint32))
-    gc, ec = got["counters"], exact["counters"]
-    assert gc["shadow_rays"] == ec["shadow_rays"] == want["counters"]["shadow_rays"] > 0
-    # a superset of the nodes, by a small margin
-    assert ec["inner_visits"] <= gc["inner_visits"] <= 1.1 * ec["inner_visits"] and ec["tri_tests"] <= gc["tri_tests"] <= 1.1 * ec["tri_tests"]
+    gc, ec, wc = got["counters"], exact["counters"], want["counters"]
+    assert gc["shadow_rays"] == ec["shadow_rays"] == wc["shadow_rays"] > 0
+    assert gc["inner_visits"] == wc["inner_visits"] and gc["tri_tests"] == wc["tri_tests"]
+    # two levels per visit: fewer node visits than the level-by-level walk; a superset of the leaves, by a small margin
+    assert gc["inner_visits"] < ec["inner_visits"] and ec["tri_tests"] <= gc["tri_tests"] <= 1.1 * ec["tri_tests"]
+
+
+@pytest.mark.parametrize("cap", [0, 2, 5])
+def test_coarse_shadow_stack_overflow(orc, scenes, gpu, monkeypatch, cap):
+    """A wide node can leave three siblings pending, the stack holds levels + 1 entries: a query that wants more is
+    answered by the exact walk.  With the capacity lowered (SRT_WIDE_CAP, read when a scene is created, by the library
+    and by the oracle) that path runs for many queries - all of them at 0: the frames must not change."""
+    d = dict(scenes("monkey"))
+    feat = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
+    d["lights"] = np.concatenate([np.asarray(d["lights"], np.float32).reshape(-1, orc.LIGHT_STRIDE),
+                                  np.asarray(orc.parallelogram_light((-0.3, 1.4, -0.3), (0.6, 0, 0), (0, 0, 0.6), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1)),
+                                             np.float32).reshape(1, -1)])
+    gb0 = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    full = gb0.render(srt.make_camera(96, 72), feat, flags=srt.RENDER_STATS)
+    monkeypatch.setenv("SRT_WIDE_CAP", str(cap))
+    ob, gb = orc.Bvh(d, orc.F_ACCEL), srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    monkeypatch.delenv("SRT_WIDE_CAP")
+    want = ob.render(orc.make_camera(96, 72), feat)
+    got = gb.render(srt.make_camera(96, 72), feat, flags=srt.RENDER_STATS)
+    _compare_frames(got, want, f"wide stack capacity {cap}")
+    assert np.array_equal(got["rgb"].view(np.uint32), full["rgb"].view(np.uint32))
+    # the lowered capacity did send queries the other way (the work of the two sides is not compared here: the exact
+    # walk of the kernels stops at a hit below 0.99, the oracle's closest-hit walk goes on to its end)
+    assert got["counters"]["inner_visits"] != full["counters"]["inner_visits"]
+    assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] == full["counters"]["shadow_rays"]
 
 
 @pytest.mark.parametrize("policy", ["reference", "cull", "coarse"])
