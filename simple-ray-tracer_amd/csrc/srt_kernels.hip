@@ -173,6 +173,7 @@ struct Walk {
     f3 o, d;
     RayRcp rr;
     f3 qi, qc; /* coarse shadow walk: slab value of grid coordinate q is q * qi + qc */
+    uint32_t qsx, qsy, qsz; /* ... and per axis 16 where the ray runs towards smaller coordinates (its near bound is the upper one), else 0 */
     float T, C;
     uint32_t cur, hitTri;
     int sp;
@@ -895,12 +896,12 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #ifndef SRT_SVOTE_INNER_W
 /* Vote weights of the shadow walk, box step : leaf step (dragon / teapot shadow launch: 1:2 141.4 / 0.752 ms, 3:4 138.7 /
  * 0.746, 1:1 139.2 / 0.759, 4:3 141.6 / 0.767) */
-#define SRT_SVOTE_INNER_W 3
-#define SRT_SVOTE_LEAF_W 4
+#define SRT_SVOTE_INNER_W 1
+#define SRT_SVOTE_LEAF_W 3
 #endif
 #ifndef SRT_SHADOW_MORE_STEPS
 #define SRT_SHADOW_MORE_STEPS 5  /* box steps a trip may add to its first one ... */
-#define SRT_SHADOW_MORE_MIN 16u  /* ... while at least this many lanes can take one */
+#define SRT_SHADOW_MORE_MIN 32u  /* ... while at least this many lanes can take one */
 #endif
 #ifndef SRT_SHADOW_CHUNK_MAX
 #define SRT_SHADOW_CHUNK_MAX 1024u /* most shadow queries a wave draws from the shared counter at a time */
@@ -1126,7 +1127,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_widen(const float4* __restrict__ 
     }
     uint4 slot[4];
     for (int k = 0; k < 4; ++k)
-        slot[k] = make_uint4(0u, 0u, 0u, SRT_WIDE_EMPTY);
+        slot[k] = make_uint4(0x0000FFFFu, 0x0000FFFFu, 0x0000FFFFu, SRT_WIDE_EMPTY); /* lower 65535, upper 0: never met */
     int w = 0;
     for (int k = 0; k < used; ++k) {
         const uint32_t cnt = (ref[k] >> 24) & 0x7Fu;
@@ -1156,17 +1157,24 @@ SRT_DI bool coarse_ray(const SceneDev& sc, Walk& w)
     const float ox = (w.o.x - sc.root_lo[0]) * sc.q_scale[0] + 1.0f, oy = (w.o.y - sc.root_lo[1]) * sc.q_scale[1] + 1.0f, oz = (w.o.z - sc.root_lo[2]) * sc.q_scale[2] + 1.0f;
     w.qi.x = 1.0f / (w.d.x * sc.q_scale[0]), w.qi.y = 1.0f / (w.d.y * sc.q_scale[1]), w.qi.z = 1.0f / (w.d.z * sc.q_scale[2]);
     w.qc.x = -(ox * w.qi.x), w.qc.y = -(oy * w.qi.y), w.qc.z = -(oz * w.qi.z);
+    w.qsx = w.qi.x < 0.0f ? 16u : 0u, w.qsy = w.qi.y < 0.0f ? 16u : 0u, w.qsz = w.qi.z < 0.0f ? 16u : 0u;
     const float lim_lo = -65536.0f, lim_hi = 131072.0f;
     return ox >= lim_lo && ox <= lim_hi && oy >= lim_lo && oy <= lim_hi && oz >= lim_lo && oz <= lim_hi;
 }
 
+/* Does the ray meet the slot's box within t in [0, 1]?  Each axis word holds lower | upper << 16; rotating it by 16
+ * where the ray runs towards smaller coordinates puts the NEAR bound into the low half, so t_in is the largest of the
+ * three low-half slab values and t_out the smallest of the three high-half ones: what the per-axis min / max of the
+ * slab test select (the slab value is monotone in the bound), without computing them.  An unused slot holds
+ * lower = 65535, upper = 0 on every axis: its t_in exceeds its t_out whatever the ray, so it is never met. */
 SRT_DI bool coarse_meets(const uint4& b, const Walk& w)
 {
-    const float xl = __builtin_fmaf((float)(b.x & 0xFFFFu), w.qi.x, w.qc.x), xh = __builtin_fmaf((float)(b.x >> 16), w.qi.x, w.qc.x);
-    const float yl = __builtin_fmaf((float)(b.y & 0xFFFFu), w.qi.y, w.qc.y), yh = __builtin_fmaf((float)(b.y >> 16), w.qi.y, w.qc.y);
-    const float zl = __builtin_fmaf((float)(b.z & 0xFFFFu), w.qi.z, w.qc.z), zh = __builtin_fmaf((float)(b.z >> 16), w.qi.z, w.qc.z);
-    const float tin = __builtin_fmaxf(__builtin_fminf(xl, xh), __builtin_fmaxf(__builtin_fminf(yl, yh), __builtin_fminf(zl, zh)));
-    const float tout = __builtin_fminf(__builtin_fmaxf(xl, xh), __builtin_fminf(__builtin_fmaxf(yl, yh), __builtin_fmaxf(zl, zh)));
+    const uint32_t bx = __builtin_amdgcn_alignbit(b.x, b.x, w.qsx), by = __builtin_amdgcn_alignbit(b.y, b.y, w.qsy), bz = __builtin_amdgcn_alignbit(b.z, b.z, w.qsz);
+    const float xn = __builtin_fmaf((float)(bx & 0xFFFFu), w.qi.x, w.qc.x), xf = __builtin_fmaf((float)(bx >> 16), w.qi.x, w.qc.x);
+    const float yn = __builtin_fmaf((float)(by & 0xFFFFu), w.qi.y, w.qc.y), yf = __builtin_fmaf((float)(by >> 16), w.qi.y, w.qc.y);
+    const float zn = __builtin_fmaf((float)(bz & 0xFFFFu), w.qi.z, w.qc.z), zf = __builtin_fmaf((float)(bz >> 16), w.qi.z, w.qc.z);
+    const float tin = __builtin_fmaxf(xn, __builtin_fmaxf(yn, zn));
+    const float tout = __builtin_fminf(xf, __builtin_fminf(yf, zf));
     return !(tin > tout || tout < 0.0f || tin > 1.0f);
 }
 
@@ -1189,9 +1197,9 @@ SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint
         const uint4* nd = sc.wnodes + 4ull * w.cur;
         s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     }
-    /* `&`, not `&&`: all four slots are tested without branches, so the record's four quarters are requested together */
-    const bool m0 = (s0.w != SRT_WIDE_EMPTY) & coarse_meets(s0, w), m1 = (s1.w != SRT_WIDE_EMPTY) & coarse_meets(s1, w);
-    const bool m2 = (s2.w != SRT_WIDE_EMPTY) & coarse_meets(s2, w), m3 = (s3.w != SRT_WIDE_EMPTY) & coarse_meets(s3, w);
+    /* all four slots are tested, without branches: the record's four quarters are requested together (an unused slot
+     * fails the test by its box) */
+    const bool m0 = coarse_meets(s0, w), m1 = coarse_meets(s1, w), m2 = coarse_meets(s2, w), m3 = coarse_meets(s3, w);
     const bool p1 = m1 & m0, p2 = m2 & (m0 | m1), p3 = m3 & (m0 | m1 | m2);
     const int pushes = (int)p1 + (int)p2 + (int)p3;
     if (w.sp + pushes > (int)sc.wide_cap) {
@@ -1225,43 +1233,16 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
     const uint32_t cnt = (w.cur >> 24) & 0x7Fu;
     float T = 1.0f;
     bool hit = false;
-#ifdef SRT_LEAF_SERIAL
+    /* One triangle after the other, on the full record (plane, vertices and the stored second operands of the inside
+     * test).  Most visits are of a single triangle: the wide records list the triangles of small leaves one by one.
+     * (Testing a leaf's triangles in pairs and recomputing the stored operands from the vertices paid while the kernel
+     * was short of loads per lane; with the wide records it is short of vector instructions: 107.9 -> 106.1 ms.) */
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
         if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, T))
             hit = true;
     }
-#else
-    /* Two triangles at a time: both plane quarters are fetched together, and so are the remaining quarters of those
-     * whose plane is met within the ray's t, so a pair costs two waits instead of four.  The second triangle is then
-     * accepted against the t the first one left, as when they are tested one after the other. */
-    for (uint32_t k = 0; k < cnt; k += 2) {
-        const float4* r0 = sc.tris + 6ull * (first + k);
-        const bool two = k + 1 < cnt;
-        const float4* r1 = two ? r0 + 6 : r0;
-        if (COUNT)
-            st.tri += two ? 2 : 1;
-        float nt0, nt1;
-        const float4 a0 = r0[0], a1 = r1[0];
-        const bool c0 = tri_plane(a0, w.o, w.d, nt0) && nt0 <= T;
-        const bool c1 = two && tri_plane(a1, w.o, w.d, nt1) && nt1 <= T;
-        bool in0 = false, in1 = false;
-        if (c0 | c1) {
-            if (__any(c1)) {
-                /* one block without branches: the ten quarters are requested together */
-                const bool i0 = tri_inside(r0, w.o, w.d, nt0), i1 = tri_inside(r1, w.o, w.d, nt1);
-                in0 = c0 & i0, in1 = c1 & i1;
-            } else {
-                in0 = tri_inside(r0, w.o, w.d, nt0); /* no lane of the wave needs a second triangle (one-triangle leaves) */
-            }
-        }
-        if (in0)
-            T = nt0, hit = true;
-        if (in1 && nt1 <= T)
-            T = nt1, hit = true;
-    }
-#endif
     if (hit) {
         w.alive = false;
         return T < 0.99f ? 1 : 2;
