@@ -419,8 +419,11 @@ bool leaf_triangle(Ctx& c, Ray& ray, HitInfo& hit, uint32_t mesh, uint32_t ti)
     return true;
 }
 
-/* BoundingVolumeHierarchy::intersect, src/bounding_volume_hierarchy.cpp:316-393 */
-bool intersect(Ctx& c, Ray& ray, HitInfo& hit)
+/* BoundingVolumeHierarchy::intersect, src/bounding_volume_hierarchy.cpp:316-393.
+ * shadow_stop: leave as soon as a leaf has been tested with the ray's t below 0.99.  Only for shadow rays (t = 1 at
+ * the start) whose caller asks `hit && t < 0.99`: t never grows, so the answer is decided there.  That is how the HIP
+ * path's exact shadow walk counts its work; the restated coarse walk falls back to it. */
+bool intersect(Ctx& c, Ray& ray, HitInfo& hit, bool shadow_stop = false)
 {
     const orc_bvh& bvh = c.bvh;
     const orc_scene& s = bvh.s;
@@ -460,6 +463,8 @@ bool intersect(Ctx& c, Ray& ray, HitInfo& hit)
                 if (leaf_triangle(c, ray, hit, t.mesh, t.tri))
                     closest = fmin_std(closest, ray.t);
             }
+            if (shadow_stop && closest != FLT_MAX && ray.t < 0.99f)
+                return true;
         } else {
             c.cnt.inner_visits += 1;
             const int ch[2] = { next.a, next.b };
@@ -543,8 +548,12 @@ void coarse_prepare(orc_bvh& b)
         }
     }
     b.coarse_ok = !bad;
-    /* the HIP path's stack capacity for this walk: levels + 1; SRT_WIDE_CAP lowers it on both sides (tests) */
-    b.wide_cap = (size_t)b.levels + 1;
+    /* the HIP path's stack capacity for this walk: what no walk of a shallow tree can overflow (three entries per wide
+     * level and one), at most 19 and at least levels + 1; SRT_WIDE_CAP lowers it on both sides (tests) */
+    {
+        const size_t levels = (size_t)b.levels, never = 3 * (levels / 2) + 1;
+        b.wide_cap = std::max(levels + 1, std::min<size_t>(never, 19));
+    }
     if (const char* cap = std::getenv("SRT_WIDE_CAP")) {
         const long v = std::strtol(cap, nullptr, 10);
         if (v >= 0 && (size_t)v < b.wide_cap)
@@ -662,8 +671,8 @@ bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
                         pushes += 1;
                 }
             }
-            if (stack.size() + pushes > bvh.wide_cap)
-                return false; /* the HIP path's stack would not hold them: the exact walk answers */
+            if (pushes > 0 && stack.size() + 3 >= bvh.wide_cap)
+                return false; /* the HIP path wants three free entries and a spare one at any visit that stacks: the exact walk answers */
             for (int k = ns - 1; k > first && first >= 0; --k)
                 if (met[k])
                     stack.push_back(slot[k]);
@@ -718,6 +727,8 @@ float visibility(Ctx& c, V3 samplePos, const Ray& ray, const HitInfo& hit)
         bool occluded = false;
         if (shadow_coarse(c, nr, hit, occluded))
             return occluded ? 0.0f : 1.0f;
+        /* the coarse walk does not apply, or gave up: the exact walk, stopping where the HIP path's stops */
+        return (intersect(c, nr, h2, true) && (double)nr.t < 1 - 0.01) ? 0.0f : 1.0f;
     }
     /* `newRay.t < 1 - 0.01` compares in double (:62) */
     if (intersect(c, nr, h2) && (double)nr.t < 1 - 0.01)

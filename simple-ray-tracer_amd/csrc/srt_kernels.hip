@@ -1180,8 +1180,8 @@ SRT_DI bool coarse_meets(const uint4& b, const Walk& w)
 
 /* Visit of the wide node the lane stands on (miss culling only: without it no box is tested at all): the walk goes on
  * in the first slot the ray meets and stacks the other met ones, last first, so that they come off the stack in slot
- * order.  Returns true, with the walk stopped, when the stack would outgrow `cap` entries: the caller then answers the
- * query with the exact walk. */
+ * order.  Returns true, with the walk stopped, when the stack is too full for the visit (fewer than four of its
+ * wide_cap entries free and something to stack): the caller then answers the query with the exact walk. */
 template <bool COUNT>
 SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint32_t* stk, Stats& st)
 {
@@ -1190,7 +1190,7 @@ SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint
         st.box += 4;
     }
     uint4 s0, s1, s2, s3;
-    if (w.cur < sc.n_top) {
+    if (SRT_WIDE_LDS_NODES > 0u && w.cur < sc.n_top) {
         const uint4* nd = top + 4u * w.cur; /* the block's LDS copy of the top levels */
         s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     } else {
@@ -1201,24 +1201,23 @@ SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint
      * fails the test by its box) */
     const bool m0 = coarse_meets(s0, w), m1 = coarse_meets(s1, w), m2 = coarse_meets(s2, w), m3 = coarse_meets(s3, w);
     const bool p1 = m1 & m0, p2 = m2 & (m0 | m1), p3 = m3 & (m0 | m1 | m2);
-    const int pushes = (int)p1 + (int)p2 + (int)p3;
-    if (w.sp + pushes > (int)sc.wide_cap) {
+    /* A visit that stacks anything needs room for three entries and one to spare, whatever it stacks: the three stores
+     * below are then unconditional (an entry that is not wanted is overwritten by the next store or never read; a visit
+     * that stacks nothing stores to the entry above the top, which the spare one guarantees to exist) and the only
+     * branch left is this one. */
+    if ((p1 | p2 | p3) & (w.sp + 3 >= (int)sc.wide_cap)) {
         w.alive = false;
         return true;
     }
-    if (p3) {
-        stk[w.sp * SRT_SHADOW_BLOCK] = s3.w;
-        ++w.sp;
-    }
-    if (p2) {
-        stk[w.sp * SRT_SHADOW_BLOCK] = s2.w;
-        ++w.sp;
-    }
-    if (p1) {
-        stk[w.sp * SRT_SHADOW_BLOCK] = s1.w;
-        ++w.sp;
-    }
-    if (m0 || m1 || m2 || m3)
+    int sp = w.sp;
+    stk[sp * SRT_SHADOW_BLOCK] = s3.w;
+    sp += (int)p3;
+    stk[sp * SRT_SHADOW_BLOCK] = s2.w;
+    sp += (int)p2;
+    stk[sp * SRT_SHADOW_BLOCK] = s1.w;
+    sp += (int)p1;
+    w.sp = sp;
+    if (m0 | m1 | m2 | m3)
         w.cur = m0 ? s0.w : (m1 ? s1.w : (m2 ? s2.w : s3.w));
     else
         w.alive = swalk_pop(w, stk);
@@ -2181,7 +2180,21 @@ void srt_scene_destroy(srt_scene* s)
 /* Stack capacity: at most one pending left sibling per inner level. */
 static uint32_t stack_entries(const srt_scene* s) { return s->num_levels + SRT_STACK_SLACK; }
 static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) * SRT_BLOCK * sizeof(uint2); }
-static size_t shadow_lds_bytes(const srt_scene* s) { return SRT_LDS_LIGHTS * sizeof(srt_light) + SRT_WIDE_LDS_NODES * 64u + (size_t)stack_entries(s) * SRT_SHADOW_BLOCK * sizeof(uint32_t); }
+/* Entries of the shadow kernel's per-lane stacks.  The walks on binary nodes need one per level.  A wide node can leave
+ * three siblings pending and wants three free entries and a spare one whenever it stacks (swalk_inner_wide), so a tree
+ * of L levels - (L - 1 + 1) / 2 wide levels - can never overflow 3 * wide levels + 1 entries; shallow trees get that,
+ * deeper ones at least 19 (what an 18-level tree's L + 1 comes to, and what seven blocks per compute unit leave room
+ * for) and the rare query that wants more is answered by the exact walk. */
+static uint32_t shadow_stack_entries(uint32_t num_levels)
+{
+    const uint32_t wide_levels = num_levels / 2, never = 3 * wide_levels + 1;
+    const uint32_t capped = never < 19u ? never : 19u;
+    return num_levels + SRT_STACK_SLACK > capped ? num_levels + SRT_STACK_SLACK : capped;
+}
+static size_t shadow_lds_bytes(const srt_scene* s)
+{
+    return SRT_LDS_LIGHTS * sizeof(srt_light) + SRT_WIDE_LDS_NODES * 64u + (size_t)shadow_stack_entries(s->num_levels) * SRT_SHADOW_BLOCK * sizeof(uint32_t);
+}
 
 template <typename K>
 static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid, int block = SRT_BLOCK)
@@ -2413,13 +2426,8 @@ static int scene_coarsen(srt_scene* s)
         if (!(depth[i] & 1u))
             wide_of[i] = depth[i] / 2 < top_levels ? next_top++ : next_rest++;
     const uint32_t n_wide = next_rest;
-    /* Stack capacity of the wide walk: the tree's levels + 1 (deepest inner node + its leaves + 1), which the LDS
-     * stacks (num_levels + SRT_STACK_SLACK entries) always hold.  A wide node can leave three siblings pending, so a
-     * query can in principle want up to 1.5 entries per level; one that does is answered by the exact walk.
-     * SRT_WIDE_CAP lowers the capacity (tests of that path). */
-    v.wide_cap = deepest + 3;
-    if (v.wide_cap > s->num_levels + SRT_STACK_SLACK)
-        v.wide_cap = s->num_levels + SRT_STACK_SLACK;
+    /* Stack capacity of the wide walk, in entries of the shadow kernel's LDS stacks (shadow_stack_entries). */
+    v.wide_cap = shadow_stack_entries(s->num_levels);
     if (const char* cap = getenv("SRT_WIDE_CAP")) {
         const long c = strtol(cap, nullptr, 10);
         if (c >= 0 && (uint32_t)c < v.wide_cap)

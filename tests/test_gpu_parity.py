@@ -379,10 +379,12 @@ def test_coarse_shadow_stack_overflow(orc, scenes, gpu, monkeypatch, cap):
     got = gb.render(srt.make_camera(96, 72), feat, flags=srt.RENDER_STATS)
     _compare_frames(got, want, f"wide stack capacity {cap}")
     assert np.array_equal(got["rgb"].view(np.uint32), full["rgb"].view(np.uint32))
-    # the lowered capacity did send queries the other way (the work of the two sides is not compared here: the exact
-    # walk of the kernels stops at a hit below 0.99, the oracle's closest-hit walk goes on to its end)
-    assert got["counters"]["inner_visits"] != full["counters"]["inner_visits"]
-    assert got["counters"]["shadow_rays"] == want["counters"]["shadow_rays"] == full["counters"]["shadow_rays"]
+    # the lowered capacity did send queries the other way, and both sides count the same work on it (the oracle's
+    # fallback stops, like the kernels' exact shadow walk, at the first leaf that leaves t below 0.99)
+    gc, wc = got["counters"], want["counters"]
+    assert gc["inner_visits"] != full["counters"]["inner_visits"]
+    assert gc["shadow_rays"] == wc["shadow_rays"] == full["counters"]["shadow_rays"]
+    assert gc["inner_visits"] == wc["inner_visits"] and gc["tri_tests"] == wc["tri_tests"]
 
 
 @pytest.mark.parametrize("policy", ["reference", "cull", "coarse"])
