@@ -464,27 +464,27 @@ SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t see
         const srt_light* L = sc.lights + li;
         const uint32_t type = L->type;
         const uint32_t n = shadow_samples(type, features);
+        /* The reference multiplies a sample's Phong term by its visibility (0 or 1).  An occluded sample adds an exact
+         * zero to the sum (the sum is never -0, and a term is finite for finite inputs), so its term - a powf and two
+         * normalisations - is not computed at all; neighbouring hits mostly share a shadow, so whole waves skip it. */
         if (type == 0) {
-            f3 pos, col;
-            light_sample(L, seed, path, depth, li, 0, pos, col);
-            const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
-            if (n) {
-                const float v = vis[bit] ? 1.0f : 0.0f;
-                res = res + sh * v;
-                bit += 1;
-            } else {
-                res = res + sh;
+            const bool lit = n ? vis[bit] != 0 : true;
+            bit += n;
+            if (lit) {
+                f3 pos, col;
+                light_sample(L, seed, path, depth, li, 0, pos, col);
+                res = res + compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
             }
         } else {
             /* segment: 100 samples, each weighted 1/100; parallelogram: 10 x 10 samples, each weighted 1/100 */
             for (uint32_t k = 0; k < n; ++k) {
-                f3 pos, col;
-                light_sample(L, seed, path, depth, li, k, pos, col);
-                const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
-                const float v = vis[bit] ? 1.0f : 0.0f;
-                res = res + sh * v;
-                bit += 1;
+                if (vis[bit + k]) {
+                    f3 pos, col;
+                    light_sample(L, seed, path, depth, li, k, pos, col);
+                    res = res + compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
+                }
             }
+            bit += n;
         }
     }
     return res;
