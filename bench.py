@@ -27,22 +27,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+L2_PEAK_GBS = 34500.0  # MI355X aggregate L2 bandwidth (8 XCDs x 4 MiB), the microarchitecture guide's figure
 
 
-def workload(name, srt):
+def workload(name, srt, dragon_obj=None):
     standin = importlib.import_module("simple-ray-tracer_amd.standin")
     if name in ("dragon", "dragon8k"):
-        d = standin.dragon_standin(check=True)
+        if dragon_obj:
+            # the real model, through the host mirror's OBJ loader, centred and scaled to unit radius as the reference's
+            # Dragon scene loads it (reference src/scene.cpp:70-75); lights as for the stand-in
+            d = srt.Scene.from_obj(dragon_obj, normalize=True).to_arrays()
+            what = f"{os.path.basename(dragon_obj)} ({len(d['tris'])} triangles, user supplied)"
+        else:
+            d = standin.dragon_standin(check=True)
+            what = "dragon stand-in (procedural, 262144 triangles)"
         d["lights"] = standin.dragon_lights()
         feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MULTISAMPLE | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
         if name == "dragon":
             return d, dict(width=3840, height=2160, features=feat, nsx=4, nsy=2, max_depth=5, cpu_block=1, tile=None,
-                           label="dragon stand-in (procedural, 262144 triangles) 3840x2160, 8 spp (4x2 grid), shading + "
+                           label=what + " 3840x2160, 8 spp (4x2 grid), shading + "
                                  "hard shadow (point light) + soft shadow (parallelogram light, 100 samples)")
         # the stress frame: 2.12 G samples, every hit reflects (ks = 0.2) until the depth cap; a frame this size is
         # rendered in rectangles on one GPU too (the work memory of one rectangle is sized for its samples)
         return d, dict(width=7680, height=4320, features=feat | srt.F_RECURSIVE, nsx=8, nsy=8, max_depth=5, cpu_block=1, tile=(960, 540), lanes=1,
-                       label="dragon stand-in (procedural, 262144 triangles) 7680x4320, 64 spp (8x8 grid), shading + hard shadow "
+                       label=what + " 7680x4320, 64 spp (8x8 grid), shading + hard shadow "
                              "(point light) + soft shadow (parallelogram light, 100 samples) + mirror recursion (depth cap 5)")
     scene_file = os.path.join(ROOT, "tests", "golden", "scenes", name + ".npz")
     if name == "teapot":
@@ -58,37 +66,48 @@ def workload(name, srt):
     raise SystemExit(f"unknown workload {name}")
 
 
-def algorithmic_bytes(c, node_bytes=64):
-    """node_bytes per inner-node visit (64: a node record with both child boxes; 32: the coarse record the shadow walk
-    reads) + 36 B per triangle test + 48 B of ray I/O per query + 64 B of attributes per shaded hit."""
-    return node_bytes * c["inner_visits"] + 36 * c["tri_tests"] + 48 * (c["path_rays"] + c["shadow_rays"]) + 64 * c["shaded_hits"]
+def algorithmic_bytes(c, node_bytes=64, tri_bytes=36):
+    """node_bytes per inner-node visit (64: one node record, whether it holds the two child boxes of a binary node or
+    the four 16-bit boxes of a wide one) + tri_bytes per triangle test (36: the three vertex positions; 96: the whole
+    traversal record) + 48 B of ray I/O per query + 64 B of attributes per shaded hit."""
+    return node_bytes * c["inner_visits"] + tri_bytes * c["tri_tests"] + 48 * (c["path_rays"] + c["shadow_rays"]) + 64 * c["shaded_hits"]
 
 
-def cpu_baseline(d, cfg, seconds, threads):
-    """The CPU restatement with the reference's visiting rule on seeded random pixel blocks of the same frame.
-    Worker threads draw blocks from one shared list until the time budget is used (a block that holds hits costs
-    orders of magnitude more than one that misses, so blocks are small and drawn dynamically).  The spread is
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_sample(d, cfg, seconds, threads, features, block, max_blocks, rule):
+    """The CPU restatement on seeded random pixel blocks of the same frame, under the given traversal policy.
+    Worker threads draw blocks from one shared list until the list or the time budget is used up (a block that holds
+    hits costs orders of magnitude more than one that misses, so blocks are drawn dynamically).  The spread is
     estimated from eight interleaved groups of the drawn blocks (group throughput = threads x rays / CPU seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import threading
     import orc
     bvh = orc.Bvh(d, orc.F_ACCEL)
     cam = orc.make_camera(cfg["width"], cfg["height"])
-    feat = cfg["features"] & ~(orc.F_MISS_CULL | orc.F_COARSE_SHADOW)
     rng = np.random.default_rng(2026)
-    bw = cfg["cpu_block"]
+    bw = block
     nbx, nby = cfg["width"] // bw, cfg["height"] // bw
-    order = rng.permutation(nbx * nby)
+    order = rng.permutation(nbx * nby)[:max_blocks]
     it = iter(enumerate(order))
     lock = threading.Lock()
     t0 = time.perf_counter()
     deadline = t0 + seconds
     groups = 8
     g_rays, g_secs = [0] * groups, [0.0] * groups
-    totals = [0, 0, 0]
+    totals = [0, 0, 0, 0.0]
 
     def worker():
         rays = blocks = hit_blocks = 0
+        busy = 0.0
         mine = [[0, 0.0] for _ in range(groups)]
         while time.perf_counter() < deadline:
             with lock:
@@ -98,13 +117,14 @@ def cpu_baseline(d, cfg, seconds, threads):
             k, b = nb
             x, y = int(b % nbx) * bw, int(b // nbx) * bw
             ta = time.perf_counter()
-            r = bvh.render(cam, feat, nsx=cfg["nsx"], nsy=cfg["nsy"], max_depth=cfg["max_depth"], rect=(x, y, x + bw, y + bw),
+            r = bvh.render(cam, features, nsx=cfg["nsx"], nsy=cfg["nsy"], max_depth=cfg["max_depth"], rect=(x, y, x + bw, y + bw),
                            threads=1, primary=False)
             tb = time.perf_counter()
             c = r["counters"]
             n = c["path_rays"] + c["shadow_rays"]
             rays += n
             blocks += 1
+            busy += tb - ta
             hit_blocks += 1 if c["shaded_hits"] else 0
             mine[k % groups][0] += n
             mine[k % groups][1] += tb - ta
@@ -112,6 +132,7 @@ def cpu_baseline(d, cfg, seconds, threads):
             totals[0] += rays
             totals[1] += blocks
             totals[2] += hit_blocks
+            totals[3] += busy
             for g in range(groups):
                 g_rays[g] += mine[g][0]
                 g_secs[g] += mine[g][1]
@@ -122,15 +143,34 @@ def cpu_baseline(d, cfg, seconds, threads):
     for t in ts:
         t.join()
     dt = time.perf_counter() - t0
-    rays, blocks, hit_blocks = totals
+    rays, blocks, hit_blocks, busy = totals
     rates = [threads * g_rays[g] / g_secs[g] / 1e6 for g in range(groups) if g_secs[g] > 0]
     stderr = float(np.std(rates, ddof=1) / np.sqrt(len(rates))) if len(rates) > 1 else None
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "stderr": stderr,
+    # all threads busy until the list or the budget ran out: rays per CPU second times the threads (when the list runs
+    # out, the last blocks leave threads idle; wall-clock time would then understate what the cores can do)
+    value = threads * rays / busy / 1e6 if busy > 0 else 0.0
+    return {"value": value, "unit": "Mrays/s", "cores": threads, "kind": "port", "stderr": stderr,
             "sample": f"{blocks} seeded random {bw}x{bw}-pixel blocks of the same frame, {hit_blocks} of them with hits "
-                      f"({rays} rays in {dt:.1f} s; standard error over {len(rates)} interleaved groups of blocks "
-                      f"{'%.2g' % stderr if stderr is not None else 'n/a'} Mrays/s), reference visiting rule (no miss culling), {threads} threads"
-                      + ("; blocks are single pixels because one hit pixel already costs seconds under the reference rule "
-                         "(64 tiles of 32x32 pixels would take days)" if bw == 1 else "")}
+                      f"({rays} rays in {dt:.1f} s wall, {busy:.1f} CPU s; standard error over {len(rates)} interleaved groups of blocks "
+                      f"{'%.2g' % stderr if stderr is not None else 'n/a'} Mrays/s), {rule}, {threads} threads"}
+
+
+def cpu_baseline(d, cfg, seconds, threads):
+    """Two CPU figures beside the GPU's: the restatement under the REFERENCE's visiting rule (what the reference itself
+    does: an unoccluded shadow ray walks the whole tree) and under the policy the GPU runs (miss culling, shadow
+    queries on coarse boxes), on seeded pixel blocks of the same frame."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    ref_feat = cfg["features"] & ~(orc.F_MISS_CULL | orc.F_COARSE_SHADOW)
+    out = cpu_sample(d, cfg, seconds, threads, ref_feat, cfg["cpu_block"], 1 << 30, "reference visiting rule (no miss culling)")
+    if cfg["cpu_block"] == 1:
+        out["sample"] += ("; blocks are single pixels because one hit pixel already costs seconds under the reference rule "
+                          "(64 tiles of 32x32 pixels would take days)")
+    out["cpu_model"] = cpu_model()
+    same = cpu_sample(d, cfg, max(seconds, 10.0), threads, cfg["features"], 32, cfg.get("cpu_tiles", 512),
+                      "the GPU's traversal policy (miss culling, shadow queries on coarse four-wide boxes)")
+    out["same_policy"] = {k: same[k] for k in ("value", "unit", "cores", "stderr", "sample")}
+    return out
 
 
 PROFILE_KERNELS = {"trace_shadow": "void k_trace_shadow<true, false, true>", "trace_primary": "void k_trace_primary<true, false>",
@@ -220,6 +260,8 @@ def main():
     ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU, 480x270 otherwise; 960x540 for dragon8k)")
     ap.add_argument("--profile-summary", default=None, help="rocprofv3 --pmc summary (profiles/summarize.py output) to take the fabric-side "
                     "traffic and cache counters from; default: the newest profiles/*_summary.txt taken with the current kernel sources")
+    ap.add_argument("--dragon-obj", default=None, help="OBJ file of the real dragon (absent from the reference checkout) to render instead of the "
+                    "procedural stand-in; loaded, centred and scaled as the reference's Dragon scene")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-shadow-boxes", action="store_true", help="shadow queries on the full-precision node array (F_MISS_CULL alone) instead of the coarse one")
@@ -253,7 +295,7 @@ def main():
 
     srt = importlib.import_module("simple-ray-tracer_amd")
     srt.set_device(local_rank)
-    d, cfg = workload(args.workload, srt)
+    d, cfg = workload(args.workload, srt, args.dragon_obj)
     if args.exact_shadow_boxes:
         cfg["features"] &= ~srt.F_COARSE_SHADOW
         PROFILE_KERNELS["trace_shadow"] = "void k_trace_shadow<true, false, false>"
@@ -292,12 +334,14 @@ def main():
         ev.record(lane()[1])
         return ev
 
-    def one_step(flags):
+    def one_step(flags, features=None):
         """One frame: this rank's share of the tiles (enqueued on the lanes' streams, written straight into the
         rank's tile buffer in HBM), then the gather to rank 0."""
+        feat = cfg["features"] if features is None else features
+
         def render_tile(rect, slot):
             b, stream = lane()
-            p = b.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rect, flags)
+            p = b.params(cam, feat, cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, rect, flags)
             b.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], stream.cuda_stream)
 
         t_a = time.perf_counter()
@@ -360,29 +404,44 @@ def main():
     rays_per_frame = float(rays.item()) / args.steps
     times = kernel_times()
 
-    # algorithmic work of each kernel family, from one more (untimed) frame with the counting kernels
+    # work of each kernel family, from one more (untimed) frame with the counting kernels ...
     read_kernel_counters()
     one_step(srt.RENDER_STATS)
     fence()
     fam = read_kernel_counters()
+    # ... and the same frame once more under plain miss culling on the binary tree's full-precision boxes: the visits the
+    # ALGORITHM asks for (one 64-byte node per inner visit, level by level), whatever node encoding the timed kernels walk
+    fam_s1 = fam
+    if cfg["features"] & srt.F_COARSE_SHADOW:
+        one_step(srt.RENDER_STATS, cfg["features"] & ~srt.F_COARSE_SHADOW)
+        fence()
+        fam_s1 = read_kernel_counters()
 
     if rank == 0:
         dominant = max(times, key=lambda n: times[n]["ms"])
         launches_timed = max(times[dominant]["launches"], 1)
         avg_ms = times[dominant]["ms"] / launches_timed
         launches_per_frame = launches_timed / args.steps
-        # the shadow walk on coarse boxes reads 32-byte node records; every other walk the 64-byte ones
-        coarse = bool(cfg["features"] & srt.F_COARSE_SHADOW)
-        node_bytes = {n: (32 if (n == "trace_shadow" and coarse) else 64) for n in fam}
-        bytes_per_launch = algorithmic_bytes(fam[dominant], node_bytes[dominant]) / max(launches_per_frame, 1e-9)
-        full_record_bytes_per_launch = algorithmic_bytes(fam[dominant]) / max(launches_per_frame, 1e-9)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # The records the traversal kernels read (nodes + triangle stream, 33 MB on the dragon stand-in) never leave
-        # the caches, so the ceiling that prices them is a cache's gather rate, not HBM: measured here, on this GPU,
-        # by a probe that gathers 64-byte records of the same arrays with no arithmetic in between, once from a 2 MiB
-        # window (stays in every XCD's L2: the L2 gather ceiling) and once from all records (what a walk without any
-        # locality would get; beyond one XCD's L2, served by the Infinity Cache).
-        l2_peak, l2_window = bvh.probe_gather(2 << 20, 512)
+        secs = {n: times[n]["ms"] / args.steps * 1e-3 for n in times}
+
+        def rate(counters, n, **kw):
+            return algorithmic_bytes(counters[n], **kw) / secs[n] / 1e9 if secs[n] > 0 else 0.0
+
+        # Three ways to price the dominant kernel's launch, all against FIXED peaks (the guide's aggregate L2 bandwidth;
+        # HBM for the traffic that leaves the caches):
+        #   achieved          algorithmic bytes: 64 B per inner-node visit and 36 B per triangle test of the level-by-level
+        #                     walk under miss culling (counted by the extra frame above) + 48 B per query + 64 B per shaded
+        #                     hit, over the launch time of the kernel as it runs (which may take fewer, wider visits)
+        #   as_walked         the same formula on the visits the timed kernel really makes (a wide record is 64 B too)
+        #   requested         bytes its loads ask the caches for: 64 B per visit, the whole 96-byte record per triangle test
+        achieved = rate(fam_s1, dominant)
+        as_walked = rate(fam, dominant)
+        requested = rate(fam, dominant, tri_bytes=96)
+        bytes_per_launch = algorithmic_bytes(fam_s1[dominant]) / max(launches_per_frame, 1e-9)
+        # Context, not a peak: what this GPU serves when lanes gather 64-byte records of the same arrays with no
+        # arithmetic in between, from a 2 MiB window (stays in every XCD's L2) and from all records (a walk without
+        # locality; beyond one XCD's L2, served by the Infinity Cache).
+        probe_l2, l2_window = bvh.probe_gather(2 << 20, 512)
         ws_rate, ws_bytes = bvh.probe_gather(0, 512)
         out = {
             "metric": "Mrays/s (and ms/frame as ms_per_step), dragon 3840x2160 8spp" if args.workload == "dragon" else "Mrays/s (and ms/frame as ms_per_step)",
@@ -391,37 +450,40 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles, "traversal": "miss-cull" + (", shadow queries on coarse boxes" if cfg["features"] & srt.F_COARSE_SHADOW else ""),
+            "dtype": "f32", "data": "synthetic" if not args.dragon_obj else "user-supplied model, synthetic camera and lights",
+            "config": {"workload": cfg["label"], "tile": [tw, th], "tiles": n_tiles,
+                       "traversal": "miss-cull" + (", shadow queries on coarse four-wide nodes" if cfg["features"] & srt.F_COARSE_SHADOW else ""),
                        "rays_per_frame": rays_per_frame, "bvh_levels": bvh.num_levels, "bvh_build_upload_s": round(t_build, 3)},
-            "roofline": {"bound": "l2", "kernel": dominant, "achieved": achieved, "peak": l2_peak, "unit": "GB/s",
-                         "frac": achieved / l2_peak if l2_peak > 0 else None, "traffic": None,
-                         "peak_source": f"measured in this run: gather of 64-byte records from a {l2_window >> 10} KiB window of the node array (L2 resident), "
-                                        "no arithmetic; the microarchitecture guide quotes about 34500 GB/s for L2 streaming",
-                         "working_set_gather": {"rate": ws_rate, "bytes": ws_bytes, "unit": "GB/s",
-                                                "note": "same probe over all node and triangle records: a walk without locality"},
-                         "hbm": {"peak": HBM_PEAK_GBS, "frac_of_peak": achieved / HBM_PEAK_GBS,
-                                 "note": "for scale only: the records are cache resident, the kernel's HBM-side traffic is `traffic`"},
+            "roofline": {"bound": "l2", "kernel": dominant, "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / L2_PEAK_GBS, "traffic": None,
+                         "peak_source": "aggregate L2 bandwidth of the microarchitecture guide (the records never leave the caches: see traffic / hbm_frac)",
+                         "frac_l2": achieved / L2_PEAK_GBS,
+                         "frac_l2_as_walked": as_walked / L2_PEAK_GBS,
+                         "frac_l2_bytes_requested": requested / L2_PEAK_GBS,
+                         "achieved_as_walked": as_walked, "achieved_bytes_requested": requested,
+                         "gather_probe": {"l2_window_rate": probe_l2, "l2_window_bytes": l2_window, "all_records_rate": ws_rate, "all_records_bytes": ws_bytes,
+                                          "unit": "GB/s", "note": "64-byte record gathers with no arithmetic, this GPU, this scene: context, not the peak"},
                          "avg_launch_ms": avg_ms, "launches_timed": launches_timed,
                          "concurrent_lanes": len(lanes),  # > 1: launches of different tiles overlap, so do their timed intervals
                          "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "node_record_bytes": node_bytes[dominant],
-                         # the same visits priced at 64 bytes per node visit, the full record (what a walk on uncompressed
-                         # nodes would have to read for them): comparable across node encodings, may exceed the gather peak
-                         "at_full_node_records": {"achieved": full_record_bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
-                                                  "over_peak": full_record_bytes_per_launch / (avg_ms * 1e-3) / 1e9 / l2_peak if avg_ms > 0 and l2_peak > 0 else None},
                          "kernel_ms_per_frame": {n: times[n]["ms"] / args.steps for n in times},
-                         # the same achieved / peak ratio for every traversal family (per frame: bytes over summed launch time)
-                         "by_kernel": {n: {"achieved": algorithmic_bytes(fam[n], node_bytes[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9,
-                                           "frac": algorithmic_bytes(fam[n], node_bytes[n]) / (times[n]["ms"] / args.steps * 1e-3) / 1e9 / l2_peak}
-                                       for n in times if n.startswith("trace_") and times[n]["ms"] > 0 and l2_peak > 0},
-                         "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]}},
+                         # the same ratios for every traversal family (per frame: bytes over summed launch time)
+                         "by_kernel": {n: {"achieved": rate(fam_s1, n), "frac": rate(fam_s1, n) / L2_PEAK_GBS, "frac_as_walked": rate(fam, n) / L2_PEAK_GBS}
+                                       for n in times if n.startswith("trace_") and secs[n] > 0},
+                         "work_per_frame": {n: fam[n] for n in fam if fam[n]["path_rays"] + fam[n]["shadow_rays"] + fam[n]["shaded_hits"]},
+                         "level_by_level_work_per_frame": {n: {k: fam_s1[n][k] for k in ("inner_visits", "tri_tests")}
+                                                           for n in fam_s1 if n.startswith("trace_") and fam_s1[n]["inner_visits"]}},
         }
         if world == 1:
             out["roofline"].update(profiled_counters(dominant, args.profile_summary, cfg["label"]))
+            tr = out["roofline"].get("traffic")
+            out["roofline"]["hbm_frac"] = tr / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr and avg_ms > 0 else None
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(d, cfg, args.cpu_seconds, threads)
+            cb = out["cpu_baseline"]
+            cb["gpu_over_cpu"] = {"reference_rule": out["value"] / cb["value"] if cb["value"] > 0 else None,
+                                  "same_policy": out["value"] / cb["same_policy"]["value"] if cb["same_policy"]["value"] > 0 else None}
         print(json.dumps(out), flush=True)
     if counter:
         if world > 1:
