@@ -165,6 +165,11 @@ def host():
     L.srth_set_device_context.argtypes = [C.c_int, C.c_int]
     L.srth_selftest_division.argtypes = [C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
     L.srth_mirror_render.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int, _f32p]
+    L.srth_bvh_add_replica.argtypes = [C.c_void_p, C.c_int]
+    L.srth_bvh_num_render_devices.argtypes = [C.c_void_p]
+    L.srth_mirror_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, _f32p]
+    L.srth_tiles_of.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]
+    L.srth_run_workers_selftest.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p]
     L.srth_mirror_intersect_one.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i32p]
     L.srth_mirror_final_color.argtypes = [C.c_void_p, _f32p, C.c_uint32, _f32p]
     L.srth_mirror_generate_ray.argtypes = [C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p, _f32p]
@@ -364,6 +369,12 @@ class Bvh:
 
     num_levels = property(lambda self: host().srth_bvh_num_levels(self.h))
     num_leaves = property(lambda self: host().srth_bvh_num_leaves(self.h))
+    num_render_devices = property(lambda self: host().srth_bvh_num_render_devices(self.h))
+
+    def add_replica(self, gpu):
+        """BvhInterface::addReplica: one more copy of the scene on GPU `gpu` (the same GPU may be named again); frames
+        rendered through mirror_render / mirror_render_frames are then shared tile by tile between the copies."""
+        _check(host().srth_bvh_add_replica(self.h, int(gpu)))
 
     def download(self):
         """The scene's arrays as they sit on the device, in the layout of HostBvh.flatten()."""
@@ -498,6 +509,33 @@ def mirror_render(bvh, features, width, height, num_rays=1, fovy_deg=50.0, dist=
     la, rd = np.array(look_at, np.float32), np.array(rot_deg, np.float32)
     _check(host().srth_mirror_render(bvh.h, features, width, height, fovy_deg, dist, _p(la), _p(rd), num_rays, _p(rgb)))
     return rgb
+
+
+def mirror_render_frames(bvh, features, width, height, cameras, num_rays=1, tile=(0, 0)):
+    """renderFrames: several cameras of one scene in one call (what the command-line front end does with its [[cameras]]).
+    cameras: rows of (fovy_deg, dist, look_at xyz, rot_deg xyz); returns (n, H, W, 3)."""
+    cams = np.ascontiguousarray(cameras, np.float32).reshape(-1, 8)
+    rgb = np.zeros((len(cams), height, width, 3), np.float32)
+    _check(host().srth_mirror_render_frames(bvh.h, features, width, height, len(cams), _p(cams), num_rays, int(tile[0]), int(tile[1]), _p(rgb)))
+    return rgb
+
+
+def tiles_of(width, height, tile_w, tile_h):
+    """tilesOf of the host mirror: a frame's tiles (x0, y0, x1, y1; y up) in the order they are handed out."""
+    n = host().srth_tiles_of(width, height, tile_w, tile_h, None, 0)
+    out = np.zeros((n, 4), np.int32)
+    host().srth_tiles_of(width, height, tile_w, tile_h, _p(out, _i32p), n)
+    return out
+
+
+def run_workers_selftest(workers, items, fail_at=-1):
+    """runWorkers of the host mirror on a work function that only records who ran what; returns (runs per item, items per
+    worker); raises SrtError when the item fail_at threw."""
+    done, by = np.zeros(items, np.int32), np.zeros(workers, np.int32)
+    rc = host().srth_run_workers_selftest(workers, items, fail_at, _p(done, _i32p), _p(by, _i32p))
+    if rc != 0:
+        raise SrtError(host().srth_last_error().decode())
+    return done, by
 
 
 def mirror_intersect_one(bvh, ray7, features):

@@ -460,28 +460,47 @@ SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t see
         return s.kd;
     f3 res = mk3(0, 0, 0);
     unsigned long long bit = bit0;
+    /* With these, compute_shading is finite for every light sample at an ordinary distance: the normal and the view
+     * vector can be normalised, colours and exponent cannot overflow, powf gets a base in [0, 1] and an exponent >= 0. */
+    const f3 view = (o + d * T) - o;
+    const float nn = dot3(s.normal, s.normal), vv = dot3(view, view);
+    const float big = 1e18f;
+    auto small3 = [&](f3 a) { return __builtin_fabsf(a.x) < big && __builtin_fabsf(a.y) < big && __builtin_fabsf(a.z) < big; };
+    bool tame = nn >= 1e-30f && nn <= 1e30f && vv >= 1e-30f && vv <= 1e30f && small3(s.kd) && small3(s.ks) && s.shininess >= 0.0f && s.shininess < big
+        && small3(o + d * T);
+    for (uint32_t li = 0; li < sc.n_lights && tame; ++li) {
+        /* light colours (every float of the record after the first three is a colour or an edge) and positions */
+        for (int k = 0; k < 21; ++k)
+            tame = tame && __builtin_fabsf(sc.lights[li].f[k]) < big;
+    }
     for (uint32_t li = 0; li < sc.n_lights; ++li) {
         const srt_light* L = sc.lights + li;
         const uint32_t type = L->type;
         const uint32_t n = shadow_samples(type, features);
-        /* The reference multiplies a sample's Phong term by its visibility (0 or 1).  An occluded sample adds an exact
-         * zero to the sum (the sum is never -0, and a term is finite for finite inputs), so its term - a powf and two
-         * normalisations - is not computed at all; neighbouring hits mostly share a shadow, so whole waves skip it. */
+        /* The reference multiplies a sample's Phong term by its visibility (0 or 1).  The term of an occluded sample - a
+         * powf and two normalisations - is not computed where the product is known to be an exact zero that leaves the
+         * sum as it is: the hit's own inputs are tame (`tame`, below) and the shadow kernel found the direction to the
+         * sample of ordinary length (visibility byte 0; 2 marks an occluded sample it could not vouch for).  Otherwise
+         * the term is computed and multiplied, so that a non-finite term poisons the sum as it does in the reference.
+         * Neighbouring hits mostly share a shadow, so whole waves skip the term. */
         if (type == 0) {
-            const bool lit = n ? vis[bit] != 0 : true;
+            const uint32_t v = n ? vis[bit] : 1u;
             bit += n;
-            if (lit) {
+            if (v != 0u || !tame) {
                 f3 pos, col;
                 light_sample(L, seed, path, depth, li, 0, pos, col);
-                res = res + compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
+                const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess);
+                res = n ? res + sh * (v == 1u ? 1.0f : 0.0f) : res + sh;
             }
         } else {
             /* segment: 100 samples, each weighted 1/100; parallelogram: 10 x 10 samples, each weighted 1/100 */
             for (uint32_t k = 0; k < n; ++k) {
-                if (vis[bit + k]) {
+                const uint32_t v = vis[bit + k];
+                if (v != 0u || !tame) {
                     f3 pos, col;
                     light_sample(L, seed, path, depth, li, k, pos, col);
-                    res = res + compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
+                    const f3 sh = compute_shading(pos, col, o, d, T, s.normal, s.kd, s.ks, s.shininess) / 100.0f;
+                    res = res + sh * (v == 1u ? 1.0f : 0.0f);
                 }
             }
             bit += n;
@@ -1251,7 +1270,8 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
 }
 
 /* Shadow queries of one recursion depth: item i = hit (i / shadows_per_hit), shadow sample (i % shadows_per_hit)
- * in the order the reference's light loop issues them; the answer is one byte per item (1 = visible).
+ * in the order the reference's light loop issues them; the answer is one byte per item (1 = visible, 0 = occluded,
+ * 2 = occluded and the shade kernel must still evaluate the sample's term: see light_contribution).
  *
  * Shadow queries differ wildly in length (an occluded one stops at its first hit, a free one walks every box
  * around its origin), so a wave that started 64 of them together would soon run mostly empty.  Instead a
@@ -1393,13 +1413,20 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                         } else if (COARSE && !coarse_ray(sc, w)) {
                             w.alive = false, redo = true; /* answered by the exact walk below */
                         }
-                    } else if (rp.features & SRT_F_ACCEL) {
-                        vis[item] = shadow_walk_exact<CULL, COUNT, false>(sc, org, dir, stk, st) ? 0 : 1;
                     } else {
-                        float Ts = 1.0f;
-                        uint32_t ht;
-                        /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
-                        vis[item] = (traverse_linear<COUNT>(sc, org, dir, Ts, ht, st) && Ts < 0.99f) ? 0 : 1;
+                        /* An occluded sample is stored as 0 when the shade kernel may skip its Phong term: the direction
+                         * to the light has an ordinary length (always so for rays in the ranges of the fast slab test),
+                         * so the term's own normalisation of it is finite.  Otherwise as 2: occluded, term to be computed. */
+                        const float dd = dot3(dir, dir);
+                        const unsigned char dark = (dd >= 1e-30f && dd <= 1e30f) ? 0 : 2;
+                        if (rp.features & SRT_F_ACCEL) {
+                            vis[item] = shadow_walk_exact<CULL, COUNT, false>(sc, org, dir, stk, st) ? dark : 1;
+                        } else {
+                            float Ts = 1.0f;
+                            uint32_t ht;
+                            /* `newRay.t < 1 - 0.01` is a double comparison in the reference; for a float t it is t < 0.99f */
+                            vis[item] = (traverse_linear<COUNT>(sc, org, dir, Ts, ht, st) && Ts < 0.99f) ? dark : 1;
+                        }
                     }
                 }
             }
@@ -2589,35 +2616,43 @@ int srt_render(srt_device* d, srt_scene* sc, const srt_render_params* p, const s
     rc = handle_work(d, sc, rp.n_samples, p->features, rp.max_depth, &wk);
     if (rc != SRT_OK)
         return rc;
-    const size_t out_px = (size_t)out->out_width * out->out_height;
     if (out->on_device) {
         rp.out_rgb = out->rgb, rp.out_mesh = out->prim_mesh, rp.out_tri = out->prim_tri, rp.out_t = out->prim_t;
     } else {
-        /* host output: render into staging buffers that mirror the caller's arrays */
-        rc = d->out_rgb.reserve(out_px * 12);
-        if (rc == SRT_OK && out->prim_mesh) rc = d->out_mesh.reserve(out_px * 4);
-        if (rc == SRT_OK && out->prim_tri) rc = d->out_tri.reserve(out_px * 4);
-        if (rc == SRT_OK && out->prim_t) rc = d->out_t.reserve(out_px * 4);
+        /* host output: the rectangle is rendered into staging buffers of its own size and its rows are copied into the
+         * caller's arrays; whatever those hold outside the rectangle is not touched, and a frame rendered rectangle by
+         * rectangle moves every pixel once */
+        const size_t px = (size_t)rp.tw * rp.th;
+        rc = d->out_rgb.reserve(px * 12);
+        if (rc == SRT_OK && out->prim_mesh) rc = d->out_mesh.reserve(px * 4);
+        if (rc == SRT_OK && out->prim_tri) rc = d->out_tri.reserve(px * 4);
+        if (rc == SRT_OK && out->prim_t) rc = d->out_t.reserve(px * 4);
         if (rc != SRT_OK)
             return rc;
         rp.out_rgb = (float*)d->out_rgb.p;
         rp.out_mesh = out->prim_mesh ? (int32_t*)d->out_mesh.p : nullptr;
         rp.out_tri = out->prim_tri ? (int32_t*)d->out_tri.p : nullptr;
         rp.out_t = out->prim_t ? (float*)d->out_t.p : nullptr;
-        /* pixels outside the rectangle keep the caller's contents */
-        HIPCHK(hipMemcpyAsync(rp.out_rgb, out->rgb, out_px * 12, hipMemcpyHostToDevice, st));
-        if (rp.out_mesh) HIPCHK(hipMemcpyAsync(rp.out_mesh, out->prim_mesh, out_px * 4, hipMemcpyHostToDevice, st));
-        if (rp.out_tri) HIPCHK(hipMemcpyAsync(rp.out_tri, out->prim_tri, out_px * 4, hipMemcpyHostToDevice, st));
-        if (rp.out_t) HIPCHK(hipMemcpyAsync(rp.out_t, out->prim_t, out_px * 4, hipMemcpyHostToDevice, st));
+        rp.out_w = rp.tw, rp.out_h = rp.th, rp.out_x0 = rp.x0, rp.out_y0 = rp.y0;
     }
     rc = dispatch_render(d, sc, rp, p->features, p->flags, st, wk);
     if (rc != SRT_OK)
         return rc;
     if (!out->on_device) {
-        HIPCHK(hipMemcpyAsync(out->rgb, rp.out_rgb, out_px * 12, hipMemcpyDeviceToHost, st));
-        if (rp.out_mesh) HIPCHK(hipMemcpyAsync(out->prim_mesh, rp.out_mesh, out_px * 4, hipMemcpyDeviceToHost, st));
-        if (rp.out_tri) HIPCHK(hipMemcpyAsync(out->prim_tri, rp.out_tri, out_px * 4, hipMemcpyDeviceToHost, st));
-        if (rp.out_t) HIPCHK(hipMemcpyAsync(out->prim_t, rp.out_t, out_px * 4, hipMemcpyDeviceToHost, st));
+        /* staging row 0 is the rectangle's top row (y = y1 - 1): row out_height - (y1 - out->y0) of the caller's array */
+        const size_t row0 = (size_t)(out->out_height - (rp.y0 + rp.th - out->y0)), col0 = (size_t)(rp.x0 - out->x0);
+        const size_t first = row0 * (size_t)out->out_width + col0;
+        HIPCHK(hipMemcpy2DAsync(out->rgb + 3 * first, (size_t)out->out_width * 12, rp.out_rgb, (size_t)rp.tw * 12, (size_t)rp.tw * 12, (size_t)rp.th,
+            hipMemcpyDeviceToHost, st));
+        if (rp.out_mesh)
+            HIPCHK(hipMemcpy2DAsync(out->prim_mesh + first, (size_t)out->out_width * 4, rp.out_mesh, (size_t)rp.tw * 4, (size_t)rp.tw * 4, (size_t)rp.th,
+                hipMemcpyDeviceToHost, st));
+        if (rp.out_tri)
+            HIPCHK(hipMemcpy2DAsync(out->prim_tri + first, (size_t)out->out_width * 4, rp.out_tri, (size_t)rp.tw * 4, (size_t)rp.tw * 4, (size_t)rp.th,
+                hipMemcpyDeviceToHost, st));
+        if (rp.out_t)
+            HIPCHK(hipMemcpy2DAsync(out->prim_t + first, (size_t)out->out_width * 4, rp.out_t, (size_t)rp.tw * 4, (size_t)rp.tw * 4, (size_t)rp.th,
+                hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     return SRT_OK;

@@ -80,19 +80,30 @@ int main(int argc, char** argv)
         options.exactShadowBoxes = config.backend.exactShadowBoxes;
         options.maxDepth = config.backend.maxDepth;
         options.seed = config.backend.seed;
-        /* The reference starts one host thread per camera; the frames of one GPU are stream ordered, so they are
-         * rendered one after the other here. */
-        int index = 0;
+        options.tileWidth = config.backend.tile.x, options.tileHeight = config.backend.tile.y;
+        /* [mi355x] gpus = [...]: one more copy of the scene per further entry */
+        for (size_t k = 1; k < config.backend.gpus.size(); ++k)
+            bvh.addReplica(config.backend.gpus[k]);
+        /* The reference starts one host thread per camera (src/main.cpp:468-487).  Here all cameras' frames go to the
+         * back end in one call: on one GPU they are rendered one after the other (its launches are stream ordered), with
+         * several GPUs the tiles of all frames form one work list that one host thread per GPU draws from. */
+        std::vector<Screen> screens;
+        std::vector<Trackball> cameras;
+        screens.reserve(config.cameras.size()), cameras.reserve(config.cameras.size());
         for (const CameraConfig& cameraConfig : config.cameras) {
-            Screen screen { config.windowSize, false };
-            screen.clear(vec3(0.0f));
-            Trackball camera { float(config.windowSize.x) / float(config.windowSize.y), radians(cameraConfig.fieldOfView), cameraConfig.distanceFromLookAt };
-            camera.setCamera(cameraConfig.lookAt, radians(cameraConfig.rotation), cameraConfig.distanceFromLookAt);
-            renderRayTracing(scene, camera, bvh, screen, features, config.backend.numRays, options);
+            screens.emplace_back(config.windowSize, false);
+            screens.back().clear(vec3(0.0f));
+            cameras.emplace_back(float(config.windowSize.x) / float(config.windowSize.y), radians(cameraConfig.fieldOfView), cameraConfig.distanceFromLookAt);
+            cameras.back().setCamera(cameraConfig.lookAt, radians(cameraConfig.rotation), cameraConfig.distanceFromLookAt);
+        }
+        std::vector<FrameJob> frames;
+        for (size_t k = 0; k < screens.size(); ++k)
+            frames.push_back({ &cameras[k], &screens[k] });
+        renderFrames(scene, bvh, frames, features, config.backend.numRays, options);
+        for (size_t index = 0; index < screens.size(); ++index) {
             const std::filesystem::path filepath = config.outputDir / (sceneName + "_" + startTime + "_cam_" + std::to_string(index) + ".bmp");
-            std::printf("Image %d saved to %s\n", index, filepath.string().c_str());
-            screen.writeBitmapToFile(filepath);
-            ++index;
+            std::printf("Image %zu saved to %s\n", index, filepath.string().c_str());
+            screens[index].writeBitmapToFile(filepath);
         }
         const auto duration = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - start).count();
         std::printf("Rendering took %lld ms, %zu images rendered.\n", (long long)duration, config.cameras.size());

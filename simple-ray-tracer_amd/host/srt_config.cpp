@@ -144,6 +144,12 @@ std::ostream& operator<<(std::ostream& os, const Config& config)
     const BackendConfig& b = config.backend;
     r.group("mi355x");
     r.entry("gpu", b.gpu);
+    if (!b.gpus.empty()) {
+        os << "    - gpus:";
+        for (int g : b.gpus)
+            os << " " << g;
+        os << ", tile " << (b.tile.x > 0 ? b.tile.x : 480) << " x " << (b.tile.y > 0 ? b.tile.y : 270) << std::endl;
+    }
     r.entry("num_rays", b.numRays);
     r.entry("enable_soft_shadow", b.enableSoftShadow);
     r.entry("enable_transparency", b.enableTransparency);
@@ -312,6 +318,21 @@ static Config fromTable(const toml::Value& table)
     if (backend.kind == toml::Value::TableKind) {
         BackendConfig& b = config.backend;
         b.gpu = (int)integerKey(backend["gpu"], "gpu", 0, 0, 1023);
+        const toml::Value& gpus = backend["gpus"];
+        if (gpus.kind != toml::Value::None) {
+            if (gpus.kind != toml::Value::ArrayKind || gpus.size() == 0 || gpus.size() > 64)
+                throw std::runtime_error("configuration: mi355x.gpus must be an array of 1 to 64 GPU numbers");
+            for (size_t k = 0; k < gpus.size(); ++k)
+                b.gpus.push_back((int)integerKey(gpus.at(k), "gpus[]", 0, 0, 1023));
+            b.gpu = b.gpus[0];
+        }
+        const toml::Value& tile = backend["tile"];
+        if (tile.kind != toml::Value::None) {
+            if (tile.kind != toml::Value::ArrayKind || tile.size() != 2)
+                throw std::runtime_error("configuration: mi355x.tile must be an array of two positive integers");
+            b.tile.x = (int)integerKey(tile.at(0), "tile[0]", 0, 8, 1 << 16);
+            b.tile.y = (int)integerKey(tile.at(1), "tile[1]", 0, 8, 1 << 16);
+        }
         b.numRays = (int)integerKey(backend["num_rays"], "num_rays", 1, 1, 64);
         b.maxDepth = (int)integerKey(backend["max_depth"], "max_depth", 5, 0, 30);
         b.seed = (uint32_t)integerKey(backend["seed"], "seed", 0, 0, 0xFFFFFFFFll);

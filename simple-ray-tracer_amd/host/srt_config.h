@@ -24,6 +24,9 @@ struct CameraConfig {
 /* Keys the reference does not have, all under the table [mi355x]; every one is optional. */
 struct BackendConfig {
     int gpu = 0;
+    std::vector<int> gpus;           /* "gpus = [0, 1, ...]": the GPUs of this node that share the frames' tiles (overrides gpu); the
+                                        same GPU may be listed more than once */
+    ivec2 tile = { 0, 0 };           /* "tile = [w, h]": tile size when several GPUs share a frame; 0: 480 x 270 */
     int numRays = 1;                 /* the reference's command-line path always renders with numRays = 1 (src/main.cpp:45,476) */
     bool enableSoftShadow = false;   /* the reference's reader never sets Features::enableSoftShadow */
     bool enableTransparency = false; /* nor extra.enableTransparency (only its viewer's check box does) */

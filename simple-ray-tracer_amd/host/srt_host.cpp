@@ -11,8 +11,11 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <atomic>
+#include <exception>
 #include <mutex>
 #include <queue>
+#include <thread>
 
 namespace srt {
 
@@ -480,26 +483,38 @@ FlatScene BoundingVolumeHierarchy::flatten(int bfsLevels) const
 
 BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     : m_pScene(pScene)
+    , m_features(features)
     , m_gpu(currentDevice())
 {
-    srt_device* dev = deviceFor(m_gpu);
     const char* hostBuild = std::getenv("SRT_HOST_BUILD");
-    if (features.extra.enableBvhSahBinning || (hostBuild && hostBuild[0] == '1')) {
+    if (features.extra.enableBvhSahBinning || (hostBuild && hostBuild[0] == '1'))
+        m_impl = new BoundingVolumeHierarchy(pScene, features);
+    try {
+        m_dev = buildOn(m_gpu);
+    } catch (...) {
+        delete m_impl;
+        throw;
+    }
+}
+
+/* One copy of the scene on the GPU behind deviceKey. */
+srt_scene* BvhInterface::buildOn(int deviceKey)
+{
+    srt_device* dev = deviceFor(deviceKey);
+    srt_scene* out = nullptr;
+    if (m_impl) {
         /* the SAH-binned tree's shape depends on the geometry: built and flattened on the host, then uploaded.
          * Depth-first node order; SRT_EXPERIMENT_BFS_LEVELS=k stores the top k levels breadth first instead (layout
          * experiments: the measured difference is within 1 %). */
-        m_impl = new BoundingVolumeHierarchy(pScene, features);
         const char* lv = std::getenv("SRT_EXPERIMENT_BFS_LEVELS");
         const FlatScene flat = m_impl->flatten(lv ? std::atoi(lv) : 0);
         const srt_scene_desc d = flat.desc();
-        if (srt_scene_upload(dev, &d, &m_dev) != SRT_OK) {
-            delete m_impl;
+        if (srt_scene_upload(dev, &d, &out) != SRT_OK)
             raise("scene upload failed");
-        }
-        return;
+        return out;
     }
     /* the reference's median-split tree: the back end builds it on the device from the triangle list */
-    const Scene& scene = *pScene;
+    const Scene& scene = *m_pScene;
     FlatScene look;
     packAppearance(scene, look);
     std::vector<float> verts;
@@ -530,12 +545,25 @@ BvhInterface::BvhInterface(Scene* pScene, const Features& features)
     b.texels = look.texels.data(), b.n_texels = look.texels.size() / 3;
     b.lights = look.lights.data(), b.n_lights = (uint32_t)look.lights.size();
     b.environment = look.environment;
-    if (srt_scene_build(dev, &b, &m_dev) != SRT_OK)
+    if (srt_scene_build(dev, &b, &out) != SRT_OK)
         raise("scene build failed");
+    return out;
 }
+
+/* Replicas live behind back-end handles of their own (contexts from 512 upwards, away from the ones setDevice hands
+ * out), so that their host threads never share a handle. */
+void BvhInterface::addReplica(int gpuId)
+{
+    const int key = (gpuId & 1023) + 1024 * (512 + (int)m_replicas.size());
+    m_replicas.push_back({ key, buildOn(key) });
+}
+
+srt_device* BvhInterface::renderDevice(size_t k) const { return deviceFor(k == 0 ? m_gpu : m_replicas[k - 1].deviceKey); }
 
 BvhInterface::~BvhInterface()
 {
+    for (const Replica& r : m_replicas)
+        srt_scene_destroy(r.scene);
     srt_scene_destroy(m_dev);
     delete m_impl;
 }
@@ -737,8 +765,9 @@ Ray Trackball::generateRay(const vec2& pixel) const
 
 /* ------------------------------------------------------------------------------------------ frame */
 
-void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const int& numRays,
-                      const RenderOptions& opt)
+/* One rectangle of one frame on copy k of the scene, into the Screen's host pixels. */
+static void renderRect(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, size_t k, Screen& screen, const Features& features, int numRays,
+                       const RenderOptions& opt, const int rect[4])
 {
     const ivec2 res = screen.resolution();
     srt_render_params p {};
@@ -748,9 +777,8 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
     p.samples_y = opt.samplesY > 0 ? opt.samplesY : numRays;
     p.max_depth = opt.maxDepth;
     p.seed = opt.seed;
-    const bool whole = opt.rect[0] == 0 && opt.rect[1] == 0 && opt.rect[2] == 0 && opt.rect[3] == 0;
-    p.rect[0] = whole ? 0 : opt.rect[0], p.rect[1] = whole ? 0 : opt.rect[1];
-    p.rect[2] = whole ? res.x : opt.rect[2], p.rect[3] = whole ? res.y : opt.rect[3];
+    for (int i = 0; i < 4; ++i)
+        p.rect[i] = rect[i];
     p.flags = (opt.stats ? SRT_RENDER_STATS : 0u) | (opt.timing ? SRT_RENDER_TIMING : 0u);
     /* the Scene's motion-blur / depth-of-field variables, reference src/scene.h:32-40 (motion blur wins, src/render.cpp:218-223) */
     p.lens.samples = features.extra.enableMotionBlur ? scene.MB_samples : scene.DOF_samples;
@@ -763,11 +791,94 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
     out.rgb = &screen.pixels()[0].x;
     out.out_width = res.x, out.out_height = res.y, out.x0 = 0, out.y0 = 0;
     out.on_device = 0;
-    if (srt_render(bvh.device(), bvh.deviceScene(), &p, &out, opt.stream) != SRT_OK)
+    if (srt_render(bvh.renderDevice(k), bvh.renderScene(k), &p, &out, k == 0 ? opt.stream : nullptr) != SRT_OK)
         raise("renderRayTracing");
+}
+
+std::vector<TileRect> tilesOf(int width, int height, int tileWidth, int tileHeight)
+{
+    std::vector<TileRect> tiles;
+    if (width <= 0 || height <= 0 || tileWidth <= 0 || tileHeight <= 0)
+        return tiles;
+    for (int y = 0; y < height; y += tileHeight)
+        for (int x = 0; x < width; x += tileWidth)
+            tiles.push_back({ x, y, std::min(x + tileWidth, width), std::min(y + tileHeight, height) });
+    /* centre first: the model usually sits there, and the dearest tiles should not be the last ones handed out */
+    const double cx = width / 2.0, cy = height / 2.0;
+    auto distance = [&](const TileRect& t) { return std::hypot((t.x0 + t.x1) / 2.0 - cx, (t.y0 + t.y1) / 2.0 - cy); };
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const TileRect& a, const TileRect& b) { return distance(a) < distance(b); });
+    return tiles;
+}
+
+void runWorkers(size_t workers, size_t items, const std::function<void(size_t, size_t)>& work)
+{
+    if (workers == 0 || items == 0)
+        return;
+    std::atomic<size_t> next { 0 };
+    std::atomic<bool> failed { false };
+    std::exception_ptr error;
+    std::mutex errorMutex;
+    auto body = [&](size_t worker) {
+        try {
+            for (;;) {
+                const size_t item = next.fetch_add(1);
+                if (item >= items || failed.load())
+                    break;
+                work(worker, item);
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(errorMutex);
+            if (!error)
+                error = std::current_exception();
+            failed.store(true);
+        }
+    };
+    std::vector<std::thread> threads;
+    for (size_t w = 1; w < workers; ++w)
+        threads.emplace_back(body, w);
+    body(0); /* the calling thread is worker 0 */
+    for (std::thread& t : threads)
+        t.join();
+    if (error)
+        std::rethrow_exception(error);
+}
+
+void renderFrames(const Scene& scene, const BvhInterface& bvh, const std::vector<FrameJob>& frames, const Features& features, const int& numRays,
+                  const RenderOptions& opt)
+{
+    const bool whole = opt.rect[0] == 0 && opt.rect[1] == 0 && opt.rect[2] == 0 && opt.rect[3] == 0;
+    const size_t copies = bvh.numRenderDevices();
+    struct Item {
+        size_t frame;
+        int rect[4];
+    };
+    std::vector<Item> items;
+    for (size_t f = 0; f < frames.size(); ++f) {
+        const ivec2 res = frames[f].screen->resolution();
+        if (!whole) {
+            items.push_back({ f, { opt.rect[0], opt.rect[1], opt.rect[2], opt.rect[3] } });
+        } else if (copies == 1) {
+            items.push_back({ f, { 0, 0, res.x, res.y } });
+        } else {
+            for (const TileRect& t : tilesOf(res.x, res.y, opt.tileWidth > 0 ? opt.tileWidth : 480, opt.tileHeight > 0 ? opt.tileHeight : 270))
+                items.push_back({ f, { t.x0, t.y0, t.x1, t.y1 } });
+        }
+    }
+    /* tiles of one frame land in disjoint rows and columns of its Screen, so the workers need no lock */
+    runWorkers(std::min(copies, items.size()), items.size(), [&](size_t worker, size_t i) {
+        const Item& it = items[i];
+        renderRect(scene, *frames[it.frame].camera, bvh, worker, *frames[it.frame].screen, features, numRays, opt, it.rect);
+    });
     /* reference src/render.cpp:231-233; a host-side pass over the frame, as in the reference (sequential by construction) */
     if (features.extra.enableBloomEffect && whole)
-        screen.applyBloomFilter(opt.bloomThreshold, 2 * opt.bloomBoxSize + 1);
+        for (const FrameJob& f : frames)
+            f.screen->applyBloomFilter(opt.bloomThreshold, 2 * opt.bloomBoxSize + 1);
+}
+
+void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features, const int& numRays,
+                      const RenderOptions& opt)
+{
+    renderFrames(scene, bvh, { FrameJob { &camera, &screen } }, features, numRays, opt);
 }
 
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features,

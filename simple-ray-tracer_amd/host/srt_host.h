@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <filesystem>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -207,6 +208,7 @@ struct RenderOptions {
     bool stats = false;
     bool timing = false;
     void* stream = nullptr;
+    int tileWidth = 0, tileHeight = 0; /* tiles a frame is cut into when the BVH has replicas on several GPUs; 0: 480 x 270 */
 };
 
 /* ---- BVH */
@@ -290,11 +292,28 @@ public:
     srt_scene* deviceScene() const { return m_dev; }
     srt_device* device() const;
 
+    /* Several GPUs of one node (no counterpart in the reference, which spreads a frame's rows over the OpenMP threads of
+     * one process, src/render.cpp:184-187): addReplica builds one more copy of the scene, on GPU gpuId, behind a back-end
+     * handle of its own.  renderRayTracing / renderFrames then cut every frame into tiles and one host thread per copy
+     * draws tiles from a shared counter.  The same GPU may be named more than once (its copies render side by side). */
+    void addReplica(int gpuId);
+    [[nodiscard]] size_t numRenderDevices() const { return 1 + m_replicas.size(); }
+    /* copy k (0: the one the constructor built) */
+    srt_device* renderDevice(size_t k) const;
+    srt_scene* renderScene(size_t k) const { return k == 0 ? m_dev : m_replicas[k - 1].scene; }
+
 private:
+    struct Replica {
+        int deviceKey;
+        srt_scene* scene;
+    };
+    srt_scene* buildOn(int deviceKey);
     BoundingVolumeHierarchy* m_impl = nullptr;
     Scene* m_pScene;
+    Features m_features;
     srt_scene* m_dev = nullptr;
     int m_gpu = 0;
+    std::vector<Replica> m_replicas;
 };
 
 /* ---- framebuffer */
@@ -350,5 +369,25 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features,
                       const int& numRays, const RenderOptions& options);
 vec3 getFinalColor(const Scene& scene, const BvhInterface& bvh, Ray ray, const Features& features, int rayDepth = 0);
+
+/* Several frames of one scene in one call: what the reference's command-line mode does with one host thread per camera
+ * (src/main.cpp:468-487).  The tiles of all frames form one work list, frame after frame, each frame's tiles from its
+ * centre outwards; one host thread per copy of the scene (BvhInterface::addReplica) draws from it until it is empty, so
+ * the GPUs stay busy whatever the number of cameras.  With a single copy every frame is one rectangle. */
+struct FrameJob {
+    const Trackball* camera;
+    Screen* screen;
+};
+void renderFrames(const Scene& scene, const BvhInterface& bvh, const std::vector<FrameJob>& frames, const Features& features, const int& numRays,
+                  const RenderOptions& options);
+
+/* The work list of renderFrames and its hand-out, exposed for tests: tilesOf lists a frame's tiles (x0, y0, x1, y1; y up)
+ * centre first; runWorkers calls work(worker, item) for every item in [0, items) exactly once, items handed out in order
+ * from one atomic counter to `workers` host threads, and rethrows the first exception a worker threw. */
+struct TileRect {
+    int x0, y0, x1, y1;
+};
+std::vector<TileRect> tilesOf(int width, int height, int tileWidth, int tileHeight);
+void runWorkers(size_t workers, size_t items, const std::function<void(size_t, size_t)>& work);
 
 } // namespace srt

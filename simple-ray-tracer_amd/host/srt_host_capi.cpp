@@ -2,8 +2,14 @@
  * srt_host_capi.cpp -- flat C entry points over the C++ host mirror, for ctypes / cgo-style callers
  * (tests, bench.py).  Every function returns 0 or a negative status; srth_last_error() has the message.
  */
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <exception>
+#include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include <sstream>
 
@@ -82,18 +88,19 @@ int srth_scene_add_texture(srth_scene* s, int w, int h, const float* rgb)
 /* Scene::environment from float RGB rows (top row first). */
 int srth_scene_set_environment(srth_scene* s, int w, int h, const float* rgb)
 {
-    auto im = std::make_shared<Image>();
-    im->width = w, im->height = h;
-    im->pixels.resize((size_t)w * h);
-    std::memcpy(im->pixels.data(), rgb, (size_t)w * h * 12);
-    s->scene.environment = im;
-    return 0;
+    SRTH_TRY(if (!s || !rgb || w <= 0 || h <= 0) throw std::invalid_argument("srth_scene_set_environment: null argument or non-positive size");
+             auto im = std::make_shared<Image>(); im->width = w; im->height = h; im->pixels.resize((size_t)w * (size_t)h);
+             std::memcpy(im->pixels.data(), rgb, (size_t)w * (size_t)h * 12); s->scene.environment = im)
 }
 /* Scene::environment = loadEnvironment(dataDir), i.e. <dataDir>/cube_map.jpg */
 int srth_scene_load_environment(srth_scene* s, const char* dataDir) { SRTH_TRY(s->scene.environment = loadEnvironment(dataDir)) }
 /* The Scene's motion-blur and depth-of-field variables (reference src/scene.h:32-40). */
 int srth_scene_set_lens(srth_scene* s, int mbSamples, float time0, float time1, const float* direction3, int focalLength, float aperture, int dofSamples)
 {
+    if (!s || !direction3) {
+        g_err = "srth_scene_set_lens: null argument";
+        return -1;
+    }
     s->scene.MB_samples = mbSamples, s->scene.time0 = time0, s->scene.time1 = time1;
     s->scene.directionVector = { direction3[0], direction3[1], direction3[2] };
     s->scene.focalLength = focalLength, s->scene.aperture = aperture, s->scene.DOF_samples = dofSamples;
@@ -418,6 +425,61 @@ int srth_mirror_render(const srth_bvh* b, uint32_t features, int width, int heig
              camera.setCamera({ look_at3[0], look_at3[1], look_at3[2] }, radians(vec3(rot_deg3[0], rot_deg3[1], rot_deg3[2])), dist);
              renderRayTracing(b->bvh->scene(), camera, *b->bvh, screen, featuresFromMask(features), 0.5f, 1, num_rays);
              std::memcpy(rgb, &screen.pixels()[0].x, (size_t)width * height * 12))
+}
+
+/* One more copy of the scene on GPU gpu (BvhInterface::addReplica); frames rendered through the mirror are then cut
+ * into tiles that one host thread per copy draws from a shared counter. */
+int srth_bvh_add_replica(srth_bvh* b, int gpu) { SRTH_TRY(b->bvh->addReplica(gpu)) }
+int srth_bvh_num_render_devices(const srth_bvh* b) { return (int)b->bvh->numRenderDevices(); }
+
+/* renderFrames: n_frames cameras (fovy, distance, look_at xyz, rotation xyz in degrees: 8 floats each) of one scene in one
+ * call, as the command-line front end issues them; rgb receives the frames one after the other. */
+int srth_mirror_render_frames(const srth_bvh* b, uint32_t features, int width, int height, int n_frames, const float* cameras8, int num_rays, int tile_w,
+                              int tile_h, float* rgb)
+{
+    SRTH_TRY(std::vector<Screen> screens; std::vector<Trackball> cameras; screens.reserve((size_t)n_frames); cameras.reserve((size_t)n_frames);
+             for (int k = 0; k < n_frames; ++k) {
+                 const float* c = cameras8 + 8 * k;
+                 screens.emplace_back(ivec2 { width, height });
+                 screens.back().clear(vec3(0.0f));
+                 cameras.emplace_back(float(width) / float(height), radians(c[0]), c[1]);
+                 cameras.back().setCamera({ c[2], c[3], c[4] }, radians(vec3(c[5], c[6], c[7])), c[1]);
+             }
+             std::vector<FrameJob> frames;
+             for (int k = 0; k < n_frames; ++k) frames.push_back({ &cameras[(size_t)k], &screens[(size_t)k] });
+             RenderOptions options; options.tileWidth = tile_w; options.tileHeight = tile_h;
+             renderFrames(b->bvh->scene(), *b->bvh, frames, featuresFromMask(features), num_rays, options);
+             for (int k = 0; k < n_frames; ++k)
+                 std::memcpy(rgb + (size_t)k * width * height * 3, &screens[(size_t)k].pixels()[0].x, (size_t)width * height * 12))
+}
+
+/* tilesOf: the tiles of a frame in hand-out order (4 ints each); returns their number (rects may be NULL). */
+int srth_tiles_of(int width, int height, int tile_w, int tile_h, int* rects4, int cap)
+{
+    const std::vector<TileRect> t = tilesOf(width, height, tile_w, tile_h);
+    for (size_t k = 0; rects4 && k < t.size() && (int)k < cap; ++k)
+        rects4[4 * k] = t[k].x0, rects4[4 * k + 1] = t[k].y0, rects4[4 * k + 2] = t[k].x1, rects4[4 * k + 3] = t[k].y1;
+    return (int)t.size();
+}
+
+/* runWorkers with a work function that only records who ran what (no GPU involved): done[i] counts how often item i ran,
+ * by_worker[w] how many items worker w took; fail_at >= 0 makes that item throw, and the call then returns -1 after all
+ * workers have stopped. */
+int srth_run_workers_selftest(int workers, int items, int fail_at, int* done, int* by_worker)
+{
+    SRTH_TRY(std::vector<std::atomic<int>> ran((size_t)items); std::vector<std::atomic<int>> took((size_t)workers);
+             for (auto& a : ran) a.store(0);
+             for (auto& a : took) a.store(0);
+             std::exception_ptr err;
+             try {
+                 runWorkers((size_t)workers, (size_t)items, [&](size_t w, size_t i) {
+                     if ((int)i == fail_at) throw std::runtime_error("item " + std::to_string(i) + " failed (as asked)");
+                     std::this_thread::sleep_for(std::chrono::microseconds(100 + 50 * (i % 7))); /* items of unequal length */
+                     ran[i].fetch_add(1); took[w].fetch_add(1); });
+             } catch (...) { err = std::current_exception(); }
+             for (int i = 0; i < items; ++i) done[i] = ran[(size_t)i].load();
+             for (int w = 0; w < workers; ++w) by_worker[w] = took[(size_t)w].load();
+             if (err) std::rethrow_exception(err))
 }
 
 int srth_mirror_intersect_one(const srth_bvh* b, float* ray7, uint32_t features, float* normal3, float* bary3, float* uv2, float* kd3, float* ks3,

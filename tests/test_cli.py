@@ -266,3 +266,32 @@ def test_config_lens_keys(tmp_path):
         srt.config_describe(_cfg(tmp_path) + "[mi355x]\nmb_samples = 1.5\n")
     with pytest.raises(srt.SrtError, match="seed"):
         srt.config_describe(_cfg(tmp_path) + "[mi355x]\nseed = -1\n")
+
+
+def test_config_gpus_and_tile(tmp_path):
+    text = srt.config_describe(_cfg(tmp_path) + "[mi355x]\ngpus = [2, 0, 2]\ntile = [96, 64]\n")
+    assert "- gpu: 2\n" in text and "- gpus: 2 0 2, tile 96 x 64" in text
+    assert "- gpus:" not in srt.config_describe(_cfg(tmp_path) + "[mi355x]\ngpu = 1\n")
+    for bad, what in (("gpus = []", "gpus"), ("gpus = 3", "gpus"), ("gpus = [0, 1.5]", "gpus"), ("tile = [96]", "tile"), ("tile = [96, 4]", "tile")):
+        with pytest.raises(srt.SrtError, match=what):
+            srt.config_describe(_cfg(tmp_path) + "[mi355x]\n" + bad + "\n")
+
+
+@pytest.mark.gpu
+def test_cli_shares_frames_between_scene_copies(tmp_path):
+    """[mi355x] gpus = [0, 0, 0]: three copies of the scene (all on the one GPU a test box has), one host thread each,
+    drawing the tiles of BOTH cameras' frames from one work list - the in-process counterpart of the reference's
+    thread per camera (src/main.cpp:468-487) and of its OpenMP rows (src/render.cpp:184-187).  The bitmaps are byte for
+    byte those of the single-copy run."""
+    outs = {}
+    for name, extra in (("one", ""), ("three", "[mi355x]\ngpus = [0, 0, 0]\ntile = [24, 16]\n")):
+        cfg = tmp_path / (name + ".toml")
+        cfg.write_text((_cfg(tmp_path) + CAMERAS + LIGHTS + extra).replace(str(tmp_path / "out"), str(tmp_path / name)))
+        r = subprocess.run([srt.CLI, str(cfg)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "2 images rendered." in r.stdout
+        files = sorted(glob.glob(str(tmp_path / name / "quads_groups_*_cam_*.bmp")))
+        assert len(files) == 2
+        outs[name] = [open(f, "rb").read() for f in files]
+    assert outs["one"] == outs["three"]
+    assert outs["one"][0] != outs["one"][1]

@@ -873,3 +873,25 @@ def test_host_mirror_call_sites(orc, scenes, pair):
         assert np.abs(srt.mirror_final_color(gb, ray, feat) - want_rgb[0]).max() <= RGB_TOL
     # features outside the implemented path are refused loudly (no silent fallback)
     assert any(h for h, _, _ in [srt.mirror_intersect_one(gb, srt.mirror_generate_ray((0, 0), 64 / 48), feat)])
+
+
+def test_frames_shared_between_scene_copies(gpu, scenes):
+    """BvhInterface::addReplica + renderFrames: two more copies of the scene on the same GPU (a test box has one), three
+    host threads drawing tiles of two cameras' frames from one counter.  Every frame is bit for bit the frame a single
+    copy renders as one rectangle, whatever the tile size (ragged edge tiles included)."""
+    d = dict(scenes("monkey"))
+    feat = FEATURE_SETS["recursive"] | srt.F_MULTISAMPLE | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
+    cams = [(50.0, 3.0, 0, 0, 0, 20, 20, 0), (35.0, 4.0, 0.1, -0.1, 0.0, -30, 120, 10)]
+    one = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    want = srt.mirror_render_frames(one, feat, 100, 70, cams, num_rays=2)
+    many = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    many.add_replica(0)
+    many.add_replica(0)
+    assert many.num_render_devices == 3 and one.num_render_devices == 1
+    for tile in [(37, 30), (8, 8), (0, 0)]:
+        got = srt.mirror_render_frames(many, feat, 100, 70, cams, num_rays=2, tile=tile)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), tile
+    assert want[0].max() > 0.05 and not np.array_equal(want[0], want[1])
+    # the single-frame entry point takes the same path
+    a = srt.mirror_render(many, feat, 100, 70, 2)
+    assert np.array_equal(a.view(np.uint32), want[0].view(np.uint32))

@@ -316,3 +316,32 @@ def test_bloom_filter(orc, h, w, box):
     assert_bits_equal(got, _bloom_by_hand(img, 0.5, box), "mirror vs the filter spelled out")
     if box > 1:
         assert np.abs(got - img).max() > 0.1
+
+
+def test_tile_list_covers_the_frame_centre_first():
+    """tilesOf: the work list of a frame shared between GPUs - every pixel in exactly one tile, edge tiles clipped, the
+    centre tile first (the reference hands rows to its OpenMP threads in order, src/render.cpp:184-187; here the order
+    decides which GPU is still busy at the end of the frame)."""
+    for (w, h, tw, th) in [(3840, 2160, 480, 270), (800, 600, 480, 270), (64, 48, 24, 16), (7, 5, 8, 8), (100, 70, 37, 30)]:
+        t = srt.tiles_of(w, h, tw, th)
+        cover = np.zeros((h, w), np.int32)
+        for x0, y0, x1, y1 in t:
+            assert 0 <= x0 < x1 <= w and 0 <= y0 < y1 <= h and x1 - x0 <= tw and y1 - y0 <= th
+            cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all() and len(t) == -(-w // tw) * -(-h // th)
+        centre = np.hypot((t[:, 0] + t[:, 2]) / 2 - w / 2, (t[:, 1] + t[:, 3]) / 2 - h / 2)
+        assert (np.diff(centre) >= -1e-9).all()
+    assert len(srt.tiles_of(0, 10, 8, 8)) == 0
+
+
+@pytest.mark.parametrize("workers,items", [(1, 17), (2, 64), (8, 200), (5, 3), (4, 0)])
+def test_work_list_hands_every_item_out_once(workers, items):
+    """runWorkers, the hand-out of renderFrames (one host thread per copy of the scene, one atomic counter): every item
+    runs exactly once, the work spreads over the threads, and an item that throws stops the hand-out and surfaces."""
+    done, by = srt.run_workers_selftest(workers, items)
+    assert (done == 1).all() and by.sum() == items
+    if items >= 8 * workers and workers > 1:
+        assert (by > 0).sum() >= 2  # items take 100 to 400 microseconds: no thread can have drained the list alone
+    if items > 4:
+        with pytest.raises(srt.SrtError, match="item 3 failed"):
+            srt.run_workers_selftest(workers, items, fail_at=3)
