@@ -116,6 +116,14 @@ def host():
     for p in (HIP_LIB, HOST_LIB):
         if not os.path.exists(p):
             raise SrtError(f"{p} is missing: run `make -C {HERE}` (there is no CPU fallback)")
+    # PyTorch's ROCm wheels carry their own HIP runtime.  Loaded first, it is the one libsrt_hip.so binds to (same
+    # soname) and the process has a single runtime; loaded after the system runtime that libsrt_hip.so would otherwise
+    # pull in, it would be a second one whose device initialisation fails.  So: PyTorch first, wherever it is installed
+    # (bench.py and distributed.py pass torch buffers and streams to this library anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(HOST_LIB)
     L.srth_last_error.restype = C.c_char_p
     L.srth_scene_create.restype = C.c_void_p

@@ -36,6 +36,7 @@
  *     (v = -1 for entries the reference never skips), so a pop costs one 8-byte LDS read and no box test.
  */
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -1858,7 +1859,7 @@ struct srt_device {
 
 /* Persistent-grid sizes (blocks that fit the GPU at once) of the four queue kernels. */
 struct Grids {
-    int primary = 0, secondary = 0, shadow = 0, shade = 0, shadow_coarse = 0;
+    int primary = 0, secondary = 0, secondary_refill = 0, shadow = 0, shade = 0, shadow_coarse = 0;
 };
 
 struct srt_scene {
@@ -1907,11 +1908,38 @@ int srt_device_count(int* count)
     return SRT_OK;
 }
 
+/* Paths of the HIP runtimes mapped into this process.  More than one means trouble: PyTorch's ROCm wheels carry a
+ * runtime of their own whose file name differs from the system one's, so a process that loads this library first and
+ * PyTorch afterwards ends up with two, and the second one's device initialisation fails with an unrelated message. */
+static int collect_hip_runtimes(struct dl_phdr_info* info, size_t, void* data)
+{
+    auto* found = (std::vector<std::string>*)data;
+    const char* name = info->dlpi_name ? info->dlpi_name : "";
+    const char* base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (!strncmp(base, "libamdhip64.so", 14)) {
+        bool seen = false;
+        for (const std::string& f : *found)
+            seen = seen || f == name;
+        if (!seen)
+            found->push_back(name);
+    }
+    return 0;
+}
+
 int srt_device_create(int gpu_id, srt_device** out)
 {
     if (!out)
         return fail(SRT_ERR_INVALID, "srt_device_create: null argument");
     *out = nullptr;
+    {
+        std::vector<std::string> runtimes;
+        dl_iterate_phdr(collect_hip_runtimes, &runtimes);
+        if (runtimes.size() > 1)
+            return fail(SRT_ERR_HIP, "two HIP runtimes are mapped into this process (%s and %s); only the first one loaded can use the GPU. "
+                                     "Load PyTorch (`import torch`) before this library, which then binds to PyTorch's runtime",
+                runtimes[0].c_str(), runtimes[1].c_str());
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(SRT_ERR_NO_DEVICE, "no HIP device is visible: the MI355X back end cannot run (there is no CPU fallback)");
@@ -1943,7 +1971,7 @@ int srt_device_create(int gpu_id, srt_device** out)
     if (e == hipSuccess)
         e = hipMemset(d->counters, 0, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e != hipSuccess) {
-        delete d;
+        srt_device_destroy(d); /* frees whatever was allocated before the failure */
         return fail(SRT_ERR_HIP, "device set-up failed: %s", hipGetErrorString(e));
     }
     *out = d;
@@ -2378,7 +2406,7 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
         static const char* refill_env = getenv("SRT_SECONDARY_REFILL");
         const bool refill = refill_env ? refill_env[0] == '1' : rp.n_samples >= (1u << 24);
         if (refill && (rp.features & SRT_F_ACCEL))
-            hipLaunchKernelGGL((k_trace_secondary_refill<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
+            hipLaunchKernelGGL((k_trace_secondary_refill<CULL, COUNT>), dim3(need < g.secondary_refill ? need : g.secondary_refill), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
                 path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc, wk.chunk_counters + 32 + depth);
         else
         hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
@@ -2400,6 +2428,7 @@ static int fill_grids(srt_device* d, srt_scene* sc)
     Grids& g = sc->grids[CULL ? 1 : 0][COUNT ? 1 : 0];
     int rc = persistent_grid(d, k_trace_primary<CULL, COUNT>, stack_bytes(sc), &g.primary);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary<CULL, COUNT>, stack_bytes(sc), &g.secondary);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary_refill<CULL, COUNT>, stack_bytes(sc), &g.secondary_refill);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, false>, shadow_lds_bytes(sc), &g.shadow, SRT_SHADOW_BLOCK);
     if (rc == SRT_OK && CULL) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, true>, shadow_lds_bytes(sc), &g.shadow_coarse, SRT_SHADOW_BLOCK);
     if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g.shade);

@@ -895,3 +895,43 @@ def test_frames_shared_between_scene_copies(gpu, scenes):
     # the single-frame entry point takes the same path
     a = srt.mirror_render(many, feat, 100, 70, 2)
     assert np.array_equal(a.view(np.uint32), want[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["cornell", "monkey", "dragon_standin"])
+def test_device_tree_equals_the_oracle_tree(orc, scenes, gpu, name):
+    """The node table as it sits on the device (srt_scene_download) against the oracle's (BoundingVolumeHierarchy's
+    `nodes`, reference src/bounding_volume_hierarchy.cpp:14-94), with nothing of the product in between: walked side by
+    side from the roots, every child box bit for bit, every leaf its triangles in the oracle's order, levels and counts."""
+    if name == "dragon_standin":
+        d = importlib.import_module("simple-ray-tracer_amd.standin").dragon_standin()
+    else:
+        d = scenes(name)
+    ob = orc.Bvh(d, orc.F_ACCEL)
+    got = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL).download()
+    meta, box = ob.dump()  # per node: leaf, level, a, b (leaf: first entry / count of tri_order; inner: left / right child)
+    order = ob.tri_order()
+    assert (got["num_levels"], got["num_leaves"]) == (ob.num_levels, ob.num_leaves)
+    root = len(meta) - 1
+    assert got["root_box"].tobytes() == box[root].tobytes()
+    nodes, tris = got["nodes"], got["tris"]
+    LEAF = 0x80000000
+    stack = [(got["root_ref"], root)]
+    inner = leaves = 0
+    while stack:
+        ref, o = stack.pop()
+        if ref & LEAF:
+            first, cnt = ref & 0xFFFFFF, (ref >> 24) & 0x7F
+            assert meta[o, 0] == 1 and cnt == meta[o, 3]
+            want = order[meta[o, 2]:meta[o, 2] + cnt]
+            assert np.array_equal(tris["mesh"][first:first + cnt], want[:, 0]) and np.array_equal(tris["tri"][first:first + cnt], want[:, 1])
+            leaves += 1
+            continue
+        assert meta[o, 0] == 0
+        n = nodes[ref]
+        a, b = int(meta[o, 2]), int(meta[o, 3])
+        assert n["lbox"].tobytes() == box[a].tobytes() and n["rbox"].tobytes() == box[b].tobytes(), (ref, o)
+        assert int(n["left_level"]) == meta[a, 1] == meta[b, 1] == meta[o, 1] + 1
+        inner += 1
+        stack.append((int(n["left"]), a))
+        stack.append((int(n["right"]), b))
+    assert inner == len(nodes) and leaves == ob.num_leaves and inner + leaves == len(meta)

@@ -345,3 +345,33 @@ def test_work_list_hands_every_item_out_once(workers, items):
     if items > 4:
         with pytest.raises(srt.SrtError, match="item 3 failed"):
             srt.run_workers_selftest(workers, items, fail_at=3)
+
+
+def _child(code):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root)
+
+
+def test_one_hip_runtime_per_process():
+    """PyTorch's ROCm wheels ship a HIP runtime of their own.  Whoever loads libsrt_hip.so first and PyTorch afterwards has
+    two runtimes in the process, and the second cannot initialise the device.  The package therefore loads PyTorch first
+    (one runtime, whichever order the caller imports in), and the library itself names the problem when it finds two."""
+    import torch  # noqa: F401  (skips nothing: the container has it)
+    count = ("import re; maps = open('/proc/self/maps').read(); "
+             "print('RUNTIMES', len({m for m in re.findall(r'\\S*libamdhip64\\S*', maps)}))")
+    # the package first, torch second: one runtime, and torch still answers
+    r = _child("import importlib; srt = importlib.import_module('simple-ray-tracer_amd'); srt.host(); import torch; "
+               "print('CUDA', torch.cuda.is_available()); " + count)
+    assert r.returncode == 0 and "RUNTIMES 1" in r.stdout and "CUDA" in r.stdout, r.stdout + r.stderr
+    # the bare library first (what an integrator without the package might do), torch second: the library says what is wrong
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "simple-ray-tracer_amd", "csrc", "libsrt_hip.so")
+    r = _child(f"import ctypes; L = ctypes.CDLL({lib!r}); import torch; " + count + "; "
+               "L.srt_last_error.restype = ctypes.c_char_p; h = ctypes.c_void_p(); rc = L.srt_device_create(0, ctypes.byref(h)); "
+               "print('RC', rc, L.srt_last_error().decode())")
+    assert r.returncode == 0, r.stderr
+    if "RUNTIMES 2" in r.stdout:
+        assert "RC -2" in r.stdout and "two HIP runtimes" in r.stdout and "import torch" in r.stdout, r.stdout
+    else:  # a PyTorch that uses the system runtime: nothing to complain about
+        assert "RUNTIMES 1" in r.stdout, r.stdout

@@ -84,3 +84,31 @@ def test_noalloc_refusals():
     import ctypes as C
     assert srt.host().srth_render_noalloc(bvh.h, C.byref(p), C.byref(o), None) != 0
     assert "device memory" in srt.host().srth_last_error().decode()
+
+
+def test_noalloc_allocates_nothing():
+    """What the entry point exists for: after one warm-up call, further calls leave the GPU's free memory exactly where it
+    was (hipMemGetInfo through torch; srt_render with a larger rectangle right after does move it, which shows that the
+    probe sees the library's allocations)."""
+    import torch
+    srt.set_device(0, context=7)  # a back-end handle of its own: its work buffers have not been grown by other tests
+    bvh = srt.Bvh(srt.Scene.from_arrays(_scene("monkey")), srt.F_ACCEL)
+    srt.set_device(0)
+    feat = srt.F_ACCEL | srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_RECURSIVE | srt.F_MULTISAMPLE | srt.F_MISS_CULL
+    W, H = 256, 192
+    cam = srt.make_camera(W, H)
+    buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    big = torch.zeros((2160, 3840, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    p = bvh.params(cam, feat, 2, 2, 5, 0, None, 0)
+    bvh.render_device_noalloc(p, buf.data_ptr(), W, H, 0, 0, stream)  # warm-up: module load, kernel code upload
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rect in (None, (10, 10, 200, 150), (0, 0, 64, 64)):
+        bvh.render_device_noalloc(bvh.params(cam, feat, 2, 2, 5, 0, rect, 0), buf.data_ptr(), W, H, 0, 0, stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    cam4k = srt.make_camera(3840, 2160)
+    bvh.render_device(bvh.params(cam4k, feat, 2, 2, 5, 0, None, 0), big.data_ptr(), 3840, 2160, 0, 0, stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] < free0  # the allocating entry point grew the handle's work buffers
