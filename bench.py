@@ -267,6 +267,9 @@ def main():
     ap.add_argument("--exact-shadow-boxes", action="store_true", help="shadow queries on the full-precision node array (F_MISS_CULL alone) instead of the coarse one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--gather-probe", action="store_true", help="with --gpus 1: cut the frame into 480x270 tiles and run the many-rank frame path "
+                    "alone (one-rank RCCL group, tile counter and frame board in shared memory), timing the parts of the gather: what one GPU can "
+                    "tell about the fixed per-frame cost of N ranks")
     ap.add_argument("--lanes", type=int, default=None, help="back-end contexts (each with its stream) a tiled frame alternates between "
                     "(default 2; 1 for dragon8k, whose rectangles are large enough for their tails not to matter)")
     args = ap.parse_args()
@@ -287,6 +290,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 and not (hasattr(dist, "batch_isend_irecv") and hasattr(dist, "P2POp")):
         raise SystemExit("this torch.distributed has no batch_isend_irecv / P2POp: the tile gather to rank 0 needs them (PyTorch >= 1.8)")
+    probe = args.gather_probe and world == 1
+    if probe:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -306,16 +314,20 @@ def main():
     cam = srt.make_camera(W, H)
 
     tiling = importlib.import_module("simple-ray-tracer_amd.distributed")
-    tw, th = args.tile if args.tile else (cfg["tile"] if cfg["tile"] else ((W, H) if world == 1 else (480, 270)))
-    counter = None
-    if world > 1:
+    tw, th = args.tile if args.tile else (cfg["tile"] if cfg["tile"] else ((W, H) if (world == 1 and not probe) else (480, 270)))
+    counter = board = None
+    if world > 1 or probe:
         name = f"/srt_tiles_{os.environ.get('MASTER_PORT', '0')}"
+        n_rects = len(tiling.tile_rects(W, H, tw, th))
         if rank == 0:
             counter = srt.TileCounter(name, True)
+            board = srt.FrameBoard(name + "_board", True, world, n_rects)
         dist.barrier()
         if rank != 0:
             counter = srt.TileCounter(name, False)
-    tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter)
+            board = srt.FrameBoard(name + "_board", False, world, n_rects)
+    tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter, board=board)
+    gather_parts = []
     n_tiles = tiler.n_tiles
     # A frame cut into tiles alternates between two back-end contexts on two streams, so that the tail of one
     # tile's kernels overlaps the start of the next tile's (a context owns its work buffers and scene copy).
@@ -354,6 +366,7 @@ def main():
             print(f"[rank {rank}] tiles {k} render {1e3 * (t_b - t_a):.1f} ms gather {1e3 * (time.perf_counter() - t_b):.1f} ms", file=sys.stderr, flush=True)
         else:
             tiler.gather(k)
+        gather_parts.append(dict(tiler.gather_ms))
         return k
 
     def fence():
@@ -389,6 +402,7 @@ def main():
     fence()
     read_counters()
     kernel_times()
+    gather_parts.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(srt.RENDER_TIMING)
@@ -403,6 +417,15 @@ def main():
     elapsed = float(el.item())
     rays_per_frame = float(rays.item()) / args.steps
     times = kernel_times()
+    gather_ms = {key: sum(g[key] for g in gather_parts) / max(len(gather_parts), 1) for key in (gather_parts[0] if gather_parts else {})}
+    if world > 1 or probe:
+        tb = []
+        for _ in range(5):
+            ta = time.perf_counter()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tb.append(1e3 * (time.perf_counter() - ta))
+        gather_ms["barrier"] = sorted(tb)[len(tb) // 2]
 
     # work of each kernel family, from one more (untimed) frame with the counting kernels ...
     read_kernel_counters()
@@ -478,6 +501,13 @@ def main():
             out["roofline"].update(profiled_counters(dominant, args.profile_summary, cfg["label"]))
             tr = out["roofline"].get("traffic")
             out["roofline"]["hbm_frac"] = tr / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr and avg_ms > 0 else None
+        if gather_ms:
+            # per frame, rank 0's host wall clock: wait_tiles = until this rank's own tiles are done (rendering, not a cost of
+            # the gather); ids = posting and collecting the tile lists through shared memory; pixels = placing own tiles and
+            # receiving the peers'; settle = the stream synchronisation that frees the tile buffers; barrier = one
+            # dist.barrier() + device synchronisation (paid once per run, between the timed steps and the clock)
+            out["gather_ms"] = dict(gather_ms, world=world, tiles=n_tiles,
+                                    fixed_cost=sum(v for k2, v in gather_ms.items() if k2 in ("ids", "pixels", "settle")))
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(d, cfg, args.cpu_seconds, threads)
@@ -489,7 +519,8 @@ def main():
         if world > 1:
             dist.barrier()
         counter.close()
-    if world > 1:
+        board.close()
+    if world > 1 or probe:
         dist.destroy_process_group()
 
 

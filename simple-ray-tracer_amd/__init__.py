@@ -190,6 +190,12 @@ def host():
     L.srth_tilecounter_next.argtypes = [C.c_void_p, C.c_int]
     L.srth_tilecounter_reset.argtypes = [C.c_void_p, C.c_int]
     L.srth_tilecounter_close.argtypes = [C.c_void_p]
+    L.srth_frameboard_open.restype = C.c_void_p
+    L.srth_frameboard_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int]
+    L.srth_frameboard_post.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, _i32p, _i32p]
+    L.srth_frameboard_wait.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+    L.srth_frameboard_read.argtypes = [C.c_void_p, C.c_int64, C.c_int, _i32p, _i32p]
+    L.srth_frameboard_close.argtypes = [C.c_void_p]
     _host = L
     return L
 
@@ -626,3 +632,35 @@ class TileCounter:
             host().srth_tilecounter_close(self.h)
             self.h = None
 
+
+
+class FrameBoard:
+    """Per-frame record of who rendered which tile (and what it cost), shared by the per-GPU processes of a node through
+    POSIX shared memory: every process posts its list when its tiles are done and then reads everybody's.  No GPU work
+    and no collective is involved.  The creating process must open it before the others."""
+
+    def __init__(self, name, create, world, n_tiles):
+        self.world, self.n_tiles = int(world), int(n_tiles)
+        self.h = host().srth_frameboard_open(name.encode(), int(create), self.world, self.n_tiles)
+        if not self.h:
+            raise SrtError(host().srth_last_error().decode())
+
+    def post(self, frame, rank, ids, costs):
+        ids = np.ascontiguousarray(ids, np.int32)
+        costs = np.ascontiguousarray(costs, np.int32)
+        _check(host().srth_frameboard_post(self.h, int(frame), int(rank), len(ids), _p(ids, _i32p), _p(costs, _i32p)))
+
+    def collect(self, frame, timeout_s=600.0):
+        """Waits for every process's post of `frame`; returns [(ids, costs)] by rank."""
+        _check(host().srth_frameboard_wait(self.h, int(frame), int(timeout_s * 1000)))
+        out = []
+        ids, costs = np.zeros(self.n_tiles, np.int32), np.zeros(self.n_tiles, np.int32)
+        for r in range(self.world):
+            k = host().srth_frameboard_read(self.h, int(frame), r, _p(ids, _i32p), _p(costs, _i32p))
+            out.append((ids[:k].copy(), costs[:k].copy()))
+        return out
+
+    def close(self):
+        if self.h:
+            host().srth_frameboard_close(self.h)
+            self.h = None

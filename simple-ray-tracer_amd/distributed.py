@@ -3,9 +3,11 @@
 Ranks draw tile indices from a counter in shared memory (TileCounter: one atomic fetch-add per tile, so a GPU
 that lands on cheap tiles simply takes more of them) and render each tile into a slot of their own tile buffer.
 There is no exchange between ranks while rendering.  When the counter runs out, the finished tiles are
-gathered to rank 0: tile ids travel in one small all_gather, pixels in one point-to-point transfer per peer (on
-MI355X every peer has its own direct xGMI link to rank 0, so a flat gather is link-optimal; `backend="nccl"` is
-RCCL there).  The same code runs over gloo with CPU tensors, which is how it is tested without GPUs.
+gathered to rank 0: who rendered which tile (and what it cost) is posted on a board in shared memory (FrameBoard: the
+ranks are processes of one node, so this takes no GPU work, no collective and no device-to-host copy), pixels travel in
+one point-to-point transfer per peer, every rank's batched the same way (on MI355X every peer has its own direct xGMI
+link to rank 0, so a flat gather is link-optimal; `backend="nccl"` is RCCL there).  The same code runs over gloo with
+CPU tensors, which is how it is tested without GPUs.
 
 Hand-out order.  Tiles differ in cost by two orders of magnitude (background against fully covered, every sample
 casting 101 shadow rays), and with 8 GPUs the dearest tile of a 4K frame alone is most of a rank's fair share,
@@ -36,15 +38,17 @@ def tile_rects(width, height, tile_w, tile_h):
 class FrameTiler:
     """Tile bookkeeping of one rank.  `device` is where tile buffers and the frame live."""
 
-    def __init__(self, width, height, tile_w, tile_h, device, rank=0, world=1, counter=None, max_in_flight=2):
+    def __init__(self, width, height, tile_w, tile_h, device, rank=0, world=1, counter=None, max_in_flight=2, board=None):
         self.W, self.H, self.tw, self.th = width, height, tile_w, tile_h
         self.rects = tile_rects(width, height, tile_w, tile_h)
         self.n_tiles = len(self.rects)
         self.device = torch.device(device)
         self.rank, self.world, self.counter = rank, world, counter
         self.max_in_flight = max_in_flight
-        if world > 1 and counter is None:
-            raise ValueError("more than one rank needs a shared tile counter")
+        if world > 1 and (counter is None or board is None):
+            raise ValueError("more than one rank needs a shared tile counter and a frame board")
+        self.board = board  # with a board the gather takes the many-rank path even alone (how one GPU rehearses it)
+        self.gather_ms = {}  # parts of the last gather() call, host wall clock
         self.tiles = torch.zeros((self.n_tiles, tile_h, tile_w, 3), dtype=torch.float32, device=self.device)
         self.ids = torch.full((self.n_tiles,), -1, dtype=torch.int32)
         self.frame = torch.zeros((height, width, 3), dtype=torch.float32, device=self.device) if rank == 0 else None
@@ -128,30 +132,25 @@ class FrameTiler:
         """Finished tiles of every rank into rank 0's frame (Screen layout: top row first)."""
         t0 = time.perf_counter()
         self._measure(k)  # also waits for this rank's tiles, whatever streams they were rendered on
-        if self.world == 1 and not dist.is_initialized():
+        t1 = time.perf_counter()
+        if self.board is None:
             if self.n_tiles == 1 and (self.tw, self.th) == (self.W, self.H):
                 self.frame.copy_(self.tiles[0])  # one tile: rendered on the current stream, which orders the copy
             else:
                 self._place(self.ids[:k].tolist(), self.tiles)
+            t2 = time.perf_counter()
+            if self.n_tiles > 1:
                 self._settle()
+            self.gather_ms = {"wait_tiles": 1e3 * (t1 - t0), "ids": 0.0, "pixels": 1e3 * (t2 - t1), "settle": 1e3 * (time.perf_counter() - t2)}
             self.step += 1
             return
         n = self.n_tiles
-        meta = torch.full((2 * n + 1,), -1, dtype=torch.int32)
-        meta[0] = k
-        meta[1:k + 1] = self.ids[:k]
-        meta[n + 1:n + 1 + k] = self.cost_us[:k]
-        meta = meta.to(self.device)
-        metas = [torch.empty_like(meta) for _ in range(self.world)]
-        t1 = time.perf_counter()
-        dist.all_gather(metas, meta)
-        host = torch.stack(metas).cpu()
+        self.board.post(self.step, self.rank, self.ids[:k].numpy(), self.cost_us[:k].numpy())
+        records = self.board.collect(self.step)
         t2 = time.perf_counter()
-        counts = host[:, 0].tolist()
-        owners, costs = [], []
-        for r in range(self.world):
-            owners += host[r, 1:1 + counts[r]].tolist()
-            costs += host[r, n + 1:n + 1 + counts[r]].tolist()
+        counts = [len(ids) for ids, _ in records]
+        owners = [int(t) for ids, _ in records for t in ids]
+        costs = [int(c) for _, cost in records for c in cost]
         if sorted(owners) != list(range(n)):
             raise RuntimeError("tile distribution lost or duplicated a tile")
         self._reorder(owners, costs)
@@ -167,12 +166,14 @@ class FrameTiler:
             for q in reqs:
                 q.wait()
             for r, b in bufs.items():
-                self._place(host[r, 1:1 + len(b)].tolist(), b)
+                self._place(records[r][0].tolist(), b)
         elif k:
-            dist.isend(self.tiles[:k].contiguous(), dst=0).wait()
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, self.tiles[:k].contiguous(), 0)]):
+                q.wait()
+        t3 = time.perf_counter()
         self._settle()
+        t4 = time.perf_counter()
+        self.gather_ms = {"wait_tiles": 1e3 * (t1 - t0), "ids": 1e3 * (t2 - t1), "pixels": 1e3 * (t3 - t2), "settle": 1e3 * (t4 - t3)}
         if os.environ.get("SRT_BENCH_DEBUG"):
-            t3 = time.perf_counter()
-            print(f"[rank {self.rank}] gather: wait for tiles {1e3 * (t1 - t0):.1f} ms, tile ids {1e3 * (t2 - t1):.1f} ms, "
-                  f"pixels {1e3 * (t3 - t2):.1f} ms", file=sys.stderr, flush=True)
+            print(f"[rank {self.rank}] gather: " + ", ".join(f"{k2} {v:.2f} ms" for k2, v in self.gather_ms.items()), file=sys.stderr, flush=True)
         self.step += 1

@@ -586,6 +586,123 @@ void srth_tilecounter_close(srth_tilecounter* t)
     delete t;
 }
 
+/* ---- the frame board: who rendered which tile, published through shared memory.
+ * At the end of a frame every process posts the tiles it rendered and what each cost; all of them then read all records
+ * (rank 0 to know how many tiles to expect from whom, everybody to derive the next frame's hand-out order).  That used to
+ * be a collective on device tensors followed by a copy to the host; the processes of one node share memory, so it is a
+ * few cache lines and one counter here, and the GPU is not involved.  Slot = frame % SRTH_BOARD_SLOTS; a slot's `posted`
+ * counter only grows (world posts per use), so nothing is ever reset, and a process can be at most one frame ahead of
+ * the slowest one because everybody waits for everybody's post. */
+#define SRTH_BOARD_SLOTS 4
+#define SRTH_BOARD_MAX_RANKS 64
+
+struct srth_board_header {
+    std::atomic<int64_t> posted[SRTH_BOARD_SLOTS];
+    int64_t world, n_tiles;
+};
+
+struct srth_frameboard {
+    srth_board_header* head;
+    int32_t* records; /* [slot][rank][1 + 2 * n_tiles]: count, tile ids, tile costs */
+    size_t bytes;
+    std::string name;
+    bool owner;
+    size_t stride() const { return 1 + 2 * (size_t)head->n_tiles; }
+    int32_t* record(int slot, int rank) const { return records + ((size_t)slot * SRTH_BOARD_MAX_RANKS + (size_t)rank) * stride(); }
+};
+
+srth_frameboard* srth_frameboard_open(const char* name, int create, int world, int n_tiles)
+{
+    if (world < 1 || world > SRTH_BOARD_MAX_RANKS || n_tiles < 1 || n_tiles > (1 << 20)) {
+        g_err = "frame board: world must be 1..64 and n_tiles 1..2^20";
+        return nullptr;
+    }
+    const size_t head = (sizeof(srth_board_header) + 63) & ~(size_t)63;
+    const size_t bytes = head + (size_t)SRTH_BOARD_SLOTS * SRTH_BOARD_MAX_RANKS * (1 + 2 * (size_t)n_tiles) * sizeof(int32_t);
+    int fd = shm_open(name, create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+    if (fd < 0) {
+        g_err = std::string("shm_open failed for ") + name;
+        return nullptr;
+    }
+    if (create && ftruncate(fd, (off_t)bytes) != 0) {
+        close(fd);
+        g_err = "ftruncate failed on the frame board";
+        return nullptr;
+    }
+    void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) {
+        g_err = "mmap failed on the frame board";
+        return nullptr;
+    }
+    auto* b = new srth_frameboard { (srth_board_header*)p, (int32_t*)((char*)p + head), bytes, name, create != 0 };
+    if (create) {
+        for (auto& c : b->head->posted)
+            c.store(0);
+        b->head->world = world, b->head->n_tiles = n_tiles;
+    } else if (b->head->world != world || b->head->n_tiles != n_tiles) {
+        g_err = "frame board: opened with another world size or tile count than it was created with";
+        munmap(p, bytes);
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+/* This process's record of frame `frame`: count tiles with their ids and costs. */
+int srth_frameboard_post(srth_frameboard* b, int64_t frame, int rank, int count, const int32_t* ids, const int32_t* costs)
+{
+    if (!b || rank < 0 || rank >= b->head->world || count < 0 || count > b->head->n_tiles || (count && (!ids || !costs))) {
+        g_err = "frame board: bad post";
+        return -1;
+    }
+    const int slot = (int)(frame % SRTH_BOARD_SLOTS);
+    int32_t* r = b->record(slot, rank);
+    r[0] = count;
+    std::memcpy(r + 1, ids, (size_t)count * 4);
+    std::memcpy(r + 1 + b->head->n_tiles, costs, (size_t)count * 4);
+    b->head->posted[slot].fetch_add(1, std::memory_order_release);
+    return 0;
+}
+
+/* Waits until every process has posted frame `frame` (0), or timeout_ms have passed (-1). */
+int srth_frameboard_wait(srth_frameboard* b, int64_t frame, int timeout_ms)
+{
+    const int slot = (int)(frame % SRTH_BOARD_SLOTS);
+    const int64_t want = b->head->world * (frame / SRTH_BOARD_SLOTS + 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; ++spin) {
+        if (b->head->posted[slot].load(std::memory_order_acquire) >= want)
+            return 0;
+        if (spin > 2000) /* a peer is still rendering: stop burning the core it may need */
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) {
+            g_err = "frame board: timed out waiting for the other processes' tile lists";
+            return -1;
+        }
+    }
+}
+
+/* Record of `rank` for frame `frame` (after srth_frameboard_wait); returns its tile count. */
+int srth_frameboard_read(const srth_frameboard* b, int64_t frame, int rank, int32_t* ids, int32_t* costs)
+{
+    const int32_t* r = b->record((int)(frame % SRTH_BOARD_SLOTS), rank);
+    const int count = r[0];
+    std::memcpy(ids, r + 1, (size_t)count * 4);
+    std::memcpy(costs, r + 1 + b->head->n_tiles, (size_t)count * 4);
+    return count;
+}
+
+void srth_frameboard_close(srth_frameboard* b)
+{
+    if (!b)
+        return;
+    munmap((void*)b->head, b->bytes);
+    if (b->owner)
+        shm_unlink(b->name.c_str());
+    delete b;
+}
+
 /* Screen::applyBloomFilter on a frame given top row first (Screen's storage order), in place. */
 int srth_bloom(float* rgb, int width, int height, float threshold, int box_size)
 {

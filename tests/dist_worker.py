@@ -27,13 +27,16 @@ def main():
     cam = orc.make_camera(W, H)
     feat = orc.F_ACCEL | orc.F_SHADING | orc.F_HARD_SHADOW | orc.F_RECURSIVE | orc.F_MISS_CULL
     name = f"/srt_test_tiles_{os.environ['MASTER_PORT']}"
-    counter = None
+    n_tiles = len(tiling.tile_rects(W, H, tw, th))
+    counter = board = None
     if rank == 0:
         counter = srt.TileCounter(name, True)
+        board = srt.FrameBoard(name + "_board", True, world, n_tiles)
     dist.barrier()
     if rank != 0:
         counter = srt.TileCounter(name, False)
-    ft = tiling.FrameTiler(W, H, tw, th, "cpu", rank, world, counter)
+        board = srt.FrameBoard(name + "_board", False, world, n_tiles)
+    ft = tiling.FrameTiler(W, H, tw, th, "cpu", rank, world, counter, board=board)
 
     def render_tile(rect, slot):
         x0, y0, x1, y1 = rect
@@ -62,6 +65,7 @@ def main():
                  orders=torch.stack(all_orders).numpy())
     dist.barrier()
     counter.close()
+    board.close()
     dist.destroy_process_group()
 
 

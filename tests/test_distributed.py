@@ -111,3 +111,28 @@ def test_tiles_land_where_their_rectangles_say(shape):
         want[H - y1:H - y0, x0:x1] = tiles[j, th - (y1 - y0):, :x1 - x0]
     ft._place([int(t) for t in ids], tiles)
     assert torch.equal(ft.frame, want)
+
+
+def test_frame_board_posts_and_collects():
+    """FrameBoard: every rank posts the tiles it rendered, everybody reads everybody's; slots are reused every four frames
+    without any reset; a missing post times out instead of hanging."""
+    name = f"/srt_test_board_{os.getpid()}"
+    a = srt.FrameBoard(name, True, 2, 12)
+    b = srt.FrameBoard(name, False, 2, 12)
+    with pytest.raises(srt.SrtError, match="another world size"):
+        srt.FrameBoard(name, False, 3, 12)
+    for frame in range(11):
+        mine = np.arange(frame % 5, dtype=np.int32) + frame
+        a.post(frame, 0, mine, mine * 10)
+        b.post(frame, 1, [11], [frame])
+        for board in (a, b):
+            rec = board.collect(frame, timeout_s=5)
+            assert np.array_equal(rec[0][0], mine) and np.array_equal(rec[0][1], mine * 10)
+            assert rec[1][0].tolist() == [11] and rec[1][1].tolist() == [frame]
+    a.post(11, 0, [], [])
+    with pytest.raises(srt.SrtError, match="timed out"):
+        a.collect(11, timeout_s=0.05)  # rank 1 never posted frame 11
+    with pytest.raises(srt.SrtError, match="bad post"):
+        a.post(12, 5, [], [])
+    b.close()
+    a.close()

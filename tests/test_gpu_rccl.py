@@ -1,7 +1,7 @@
-"""The tile gather over RCCL on the one GPU a test box has: a process group of one rank (RCCL refuses two ranks on one
-device), so the group set-up bound to the device, the all_gather of tile ids on device tensors, the barrier and the
-placement run through RCCL; only the peer-to-peer transfer has no peer.  Runs in a child process, so that the test
-process itself never holds a process group."""
+"""The many-rank frame path on the one GPU a test box has: a process group of one rank over RCCL (RCCL refuses two ranks
+on one device), tile counter and frame board in shared memory, so the group set-up bound to the device, the posting and
+collecting of tile lists, the placement and the barrier run as they do with peers; only the peer-to-peer transfer has no
+peer.  Runs in a child process, so that the test process itself never holds a process group."""
 import os
 import subprocess
 import sys
@@ -29,7 +29,10 @@ W, H, tw, th = 96, 64, 32, 16
 cam = srt.make_camera(W, H)
 feats = srt.F_SHADING | srt.F_HARD_SHADOW | srt.F_ACCEL | srt.F_MISS_CULL
 whole = bvh.render(cam, feats, 1, 1, 0, primary=False)["rgb"]
-tiler = tiling.FrameTiler(W, H, tw, th, dev, 0, 1, None)
+name = f"/srt_test_rccl_{os.getpid()}"
+counter = srt.TileCounter(name, True)
+board = srt.FrameBoard(name + "_board", True, 1, 12)
+tiler = tiling.FrameTiler(W, H, tw, th, dev, 0, 1, counter, board=board)
 def render_tile(rect, slot):
     p = bvh.params(cam, feats, 1, 1, 0, 0, rect, 0)
     bvh.render_device(p, slot.data_ptr(), tw, th, rect[0], rect[1], torch.cuda.current_stream().cuda_stream)
@@ -40,6 +43,8 @@ for _ in range(2):  # the second frame goes out in the order the first frame's t
     torch.cuda.synchronize()
     assert k == tiler.n_tiles == 12
     assert np.array_equal(tiler.frame.cpu().numpy(), whole)
+    assert set(tiler.gather_ms) == {"wait_tiles", "ids", "pixels", "settle"}
+counter.close(); board.close()
 dist.destroy_process_group()
 print("rccl gather ok")
 """
