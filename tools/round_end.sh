@@ -5,6 +5,8 @@ T=$1
 R=$GRAFT_REPO_ROOT
 cd $R
 [ -n "$SKIP_PROFILE" ] || bash tools/profile.sh ${T}_dragon || exit 1   # SKIP_PROFILE=1: bench lines only
+# under its final name, so that the bench line below takes its traffic and cache counters from it (and records that path)
+[ -n "$SKIP_PROFILE" ] || cp gpurun_out/prof_${T}_dragon/summary.txt profiles/${T}_dragon_summary.txt
 line() { grep '^{"metric"' | tail -1; }
 timeout -k 10 300 python3 -u bench.py 2> gpurun_out/${T}_bench_dragon.err | line > gpurun_out/${T}_bench_dragon.jsonl || exit 1
 echo "dragon done"
