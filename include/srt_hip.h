@@ -52,20 +52,22 @@ extern "C" {
  * first hit).  1: additionally skip every box whose slab test fails; same result up to rounding of
  * hit points, orders of magnitude less work.  The host mirror sets it by default. */
 #define SRT_F_MISS_CULL (1u << 16)
-/* With SRT_F_MISS_CULL: shadow queries test child boxes on a 16-bit grid over the root box, rounded outwards by more
- * than a grid step, read from a half-size copy of the node array that the library derives at upload / build.  A
- * shadow query only asks whether anything lies between the point and the light, so a box that contains the child's
- * box is as good as the box itself: a superset of the nodes is visited (0.2 % more on the 262 144-triangle stand-in)
- * and the triangle tests decide as before.  The answer can differ from SRT_F_MISS_CULL alone only for a ray that a
- * triangle test accepts although the slab test of the triangle's own box rejects it (both are rounded); the coarse
- * walk then finds the occluder, as the reference's un-culled shadow walk does.  Closest-hit queries are not affected.
- * Ignored for scenes whose node table has a child box outside the root box.  The host mirror sets it by default. */
+/* With SRT_F_MISS_CULL: shadow queries test boxes on a 16-bit grid over the root box, rounded outwards by more than a
+ * grid step, two tree levels at a time: the library derives, at upload / build, one 64-byte record per inner node of even
+ * depth that holds the boxes of its four grandchildren (a child that is a leaf stands for itself; the triangles of small
+ * leaves get boxes of their own) in the order the reference's walk would pop them.  A shadow query only asks whether
+ * anything lies between the point and the light, so a box that contains the child's box is as good as the box itself: a
+ * superset of the nodes is visited and the triangle tests decide as before.  The answer can differ from SRT_F_MISS_CULL
+ * alone only for a ray that a triangle test accepts although the slab test of the triangle's own box rejects it (both are
+ * rounded); the coarse walk then finds the occluder, as the reference's un-culled shadow walk does.  Closest-hit queries
+ * are not affected.  Ignored for scenes whose node table has a child box outside the root box.  The host mirror sets it by
+ * default. */
 #define SRT_F_COARSE_SHADOW (1u << 17)
 
 #define SRT_LEAF_FLAG 0x80000000u
 #define SRT_MAX_TRIS (1u << 24)  /* triangle index field of a packed child reference */
 #define SRT_MAX_LEAF_TRIS 127u   /* count field of a packed child reference */
-#define SRT_MAX_LEVELS 30        /* per-lane traversal stack capacity is levels + 1 */
+#define SRT_MAX_LEVELS 30        /* per-lane traversal stack capacity is levels + 1 (shadow queries: at least that) */
 
 /* One inner node, 64 bytes, 64-byte aligned in device memory.  Holds BOTH children's boxes (the
  * reference tests a child's box while visiting the parent, src/bounding_volume_hierarchy.cpp:370-376)

@@ -36,7 +36,7 @@ F_DEPTH_OF_FIELD = 1 << 12  # extra.enableDepthOfField
 F_ENVIRONMENT = 1 << 13   # extra.enableEnvironmentMapping (Scene.set_environment)
 F_BLOOM = 1 << 9         # host-side pass of the C++ mirror (extra.enableBloomEffect); not a kernel flag
 F_MISS_CULL = 1 << 16    # traversal policy; clear it for the reference's exact visiting rule
-F_COARSE_SHADOW = 1 << 17  # with F_MISS_CULL: shadow queries on the half-size node array (outward-rounded 16-bit boxes)
+F_COARSE_SHADOW = 1 << 17  # with F_MISS_CULL: shadow queries on four-wide nodes of outward-rounded 16-bit boxes
 
 RENDER_STATS = 1 << 0
 RENDER_TIMING = 1 << 1

@@ -578,7 +578,7 @@ def test_dragon_full_size_properties(dragon_pair):
     strip = gb.render(cam, feat, nsx=4, nsy=2, rect=(0, 810, 3840, 1350), primary=False)["rgb"]
     assert np.array_equal(strip[810:1350].view(np.uint32), a["rgb"][810:1350].view(np.uint32))
     assert a["rgb"][810:1350].max() > 0.05 and np.isfinite(a["rgb"]).all()
-    # shadow queries on the coarse node array: the same frame bit for bit, whole (1024 queries per draw from the chunk
+    # shadow queries on the coarse four-wide nodes: the same frame bit for bit, whole (1024 queries per draw from the chunk
     # counter) and as a small rectangle (shorter chunks)
     c = gb.render(cam, feat | srt.F_COARSE_SHADOW, nsx=4, nsy=2, primary=False)
     assert c["counters"]["shadow_rays"] == a["counters"]["shadow_rays"]

@@ -90,7 +90,7 @@ def run(first, count):
                 feat |= orc.F_MULTISAMPLE | orc.F_NORMAL_INTERP
                 nsx, nsy = 2, 2
             if k in (0, 2, 7):
-                feat |= orc.F_COARSE_SHADOW       # shadow queries on the coarse node array
+                feat |= orc.F_COARSE_SHADOW       # shadow queries on the coarse four-wide nodes
             if k == 3:
                 feat &= ~orc.F_MISS_CULL          # the reference's own visiting rule
             if k == 4:
