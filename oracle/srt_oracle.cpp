@@ -583,12 +583,7 @@ bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
     for (int k = 0; k < 3; ++k)
         if (!fast_dir(d[k]) || !fast_coord(o[k]))
             return false;
-    float val;
-    Ray probe = ray;
-    if (!slab(bvh.nodes.back().box, probe, val)) {
-        occluded = false; /* the ray misses the root box */
-        return true;
-    }
+    /* no test of the root box: a ray that misses it meets none of the root's four slots (or a rounded-out one) */
     const Box& root = bvh.nodes.back().box;
     const float rlo[3] = { root.lo.x, root.lo.y, root.lo.z };
     CoarseRay cr;

@@ -1406,14 +1406,20 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                     const f3 dir = pos3 - ip;
                     const f3 org = ip + normalize3(dir) * 0.001f;
                     nShadow += 1;
-                    if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
+                    if (COARSE && (rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
+                        /* The walk on the wide records starts without a test of the root box: a ray that misses it
+                         * meets none of the root record's slots (or a rounded-out one, and then only finds what the
+                         * triangle tests accept), so the test - six exact quotients per query - decides nothing. */
+                        w.o = org, w.d = dir, w.T = 1.0f, w.C = SRT_FLT_MAX;
+                        w.cur = sc.root_ref, w.sp = 0, w.alive = true;
+                        busy = true;
+                        if (!coarse_ray(sc, w))
+                            w.alive = false, redo = true; /* answered by the exact walk below */
+                    } else if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
                         walk_begin<CULL, COUNT, true>(sc, w, org, dir, 1.0f, st);
                         busy = w.alive;
-                        if (!busy) {
+                        if (!busy)
                             vis[item] = 1; /* the ray misses the root box */
-                        } else if (COARSE && !coarse_ray(sc, w)) {
-                            w.alive = false, redo = true; /* answered by the exact walk below */
-                        }
                     } else {
                         /* An occluded sample is stored as 0 when the shade kernel may skip its Phong term: the direction
                          * to the light has an ordinary length (always so for rays in the ranges of the fast slab test),
@@ -2320,7 +2326,11 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const bool coarse = CULL && (rp.features & SRT_F_COARSE_SHADOW) && sc->view.coarse_ok;
     int g_primary = g.primary, g_secondary = g.secondary, g_shadow = coarse ? g.shadow_coarse : g.shadow, g_shade = g.shade;
     const int need = (int)((n + SRT_BLOCK - 1) / SRT_BLOCK);
+#ifdef SRT_EXPERIMENT_PRIMARY_BLOCKS
+    g_primary = need; /* one block per 256 samples: the hardware dispatcher balances the blocks */
+#else
     if (need < g_primary) g_primary = need;
+#endif
     if (need < g_secondary) g_secondary = need;
     if (need < g_shade) g_shade = need;
     const unsigned long long need_shadow = ((unsigned long long)n * sph + SRT_SHADOW_BLOCK - 1) / SRT_SHADOW_BLOCK;

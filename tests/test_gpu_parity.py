@@ -356,8 +356,12 @@ def test_coarse_shadow_boxes(orc, pair, name, res):
     gc, ec, wc = got["counters"], exact["counters"], want["counters"]
     assert gc["shadow_rays"] == ec["shadow_rays"] == wc["shadow_rays"] > 0
     assert gc["inner_visits"] == wc["inner_visits"] and gc["tri_tests"] == wc["tri_tests"]
-    # two levels per visit: fewer node visits than the level-by-level walk; a superset of the leaves, by a small margin
-    assert gc["inner_visits"] < ec["inner_visits"] and ec["tri_tests"] <= gc["tri_tests"] <= 1.1 * ec["tri_tests"]
+    # a superset of the leaves, by a small margin; two levels per visit: fewer node visits than the level-by-level walk
+    # (not in the two tiny scenes, where most shadow rays miss the root box: the wide walk has no root test and pays one
+    # visit to find that out)
+    assert ec["tri_tests"] <= gc["tri_tests"] <= 1.1 * ec["tri_tests"]
+    if name in ("monkey", "teapot"):
+        assert gc["inner_visits"] < ec["inner_visits"]
 
 
 @pytest.mark.parametrize("cap", [0, 2, 5])
