@@ -268,6 +268,10 @@ SRT_DI uint32_t mix32(uint32_t h, uint32_t k)
 }
 SRT_DI float rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim)
 {
+#ifdef SRT_EXPERIMENT_CHEAP_RAND
+    uint32_t hh = (seed ^ path) + depth * 977u + light * 131u + sample * 7919u + dim * 104729u; /* timing experiment only */
+    return (float)(hh & 0xFFFFFFu) * (1.0f / 16777216.0f);
+#endif
     uint32_t h = mix32(mix32(mix32(mix32(mix32(seed, path), depth), light), sample), dim);
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }

@@ -665,7 +665,8 @@ SRT_DI uint32_t queue_slot(bool want, uint32_t* count)
 }
 
 template <bool CULL, bool COUNT>
-__global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, RenderDev rp, HitQ hq, uint32_t* hq_count, DevCounters* cnt, float* acc)
+__global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, RenderDev rp, HitQ hq, uint32_t* hq_count, DevCounters* cnt, float* acc,
+                                                               unsigned char* nlev)
 {
     extern __shared__ uint2 lds_stack[];
     uint2* stk = lds_stack + threadIdx.x;
@@ -683,10 +684,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_primary(SceneDev sc, Render
         if (active && primary_ray(rp, s, o, d, T, px, py, sub)) {
             nPath += 1;
             hit = bvh_query<CULL, COUNT>(sc, rp.features, o, d, T, tri, stk, st);
-            if (!hit && (rp.features & SRT_F_ENVIRONMENT)) {
-                const f3 e = environment_color(sc, o, d, T);
-                acc[3ull * s] = e.x, acc[3ull * s + 1] = e.y, acc[3ull * s + 2] = e.z;
-            }
+            /* the sample's slot starts at black, or at the environment's colour: what a ray that hits nothing returns
+             * (the frame's launches need no cleared buffers: every slot that is read later is written here first) */
+            f3 e = mk3(0, 0, 0);
+            if (!hit && (rp.features & SRT_F_ENVIRONMENT))
+                e = environment_color(sc, o, d, T);
+            acc[3ull * s] = e.x, acc[3ull * s + 1] = e.y, acc[3ull * s + 2] = e.z;
+            if (nlev)
+                nlev[s] = 0;
             if (sub == 0 && (rp.out_mesh || rp.out_tri || rp.out_t)) {
                 const long long oi = out_index(rp, px, py);
                 int mesh = -1, ti = -1;
@@ -1506,6 +1511,11 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
  * parked levels from the deepest up, with the reference's operations in the reference's order.
  * Transparency: a sample's rays form a binary tree instead; their shares are weighted by the product of the factors
  * on the way (thr) and added front to back (within rounding of the reference's nested sums). */
+/* MODE 0: all of it.  A frame whose launches are few and short runs the two halves as kernels of their own, on two
+ * streams (render_impl): MODE 1 only sends on the reflection rays (the hit's attributes, the ray, the level's ks), so
+ * that the next depth's trace can start while this depth's shadow queries are still being answered; MODE 2 only
+ * evaluates the light and puts it where MODE 0 would (never used with transparency). */
+template <int MODE>
 __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count, const float4* cur_paths,
                                                        float4* next_paths, uint32_t* next_count, float* acc, float* chain, unsigned char* nlev,
                                                        const unsigned char* vis, uint32_t shadows_per_hit, DevCounters* cnt)
@@ -1528,8 +1538,11 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             pathKey = path;
             Surface sf;
             surface_at(sc, rp.features, o, d, T, tri, sf);
-            nShaded += 1;
-            const f3 Lo = light_contribution(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, vis, (unsigned long long)h * shadows_per_hit);
+            if (MODE != 1)
+                nShaded += 1;
+            f3 Lo = mk3(0, 0, 0);
+            if (MODE != 1)
+                Lo = light_contribution(sc, rp.features, rp.seed, path, (uint32_t)depth, o, d, T, sf, vis, (unsigned long long)h * shadows_per_hit);
             /* Share of this hit's own light in the sample.  With transparency (reference src/render.cpp:111-120) a
              * hit at the depth cap, or of a material with transparency above 1, returns black; a material with
              * transparency tr < 1 keeps tr of its light (and of its reflection) and passes 1 - tr on.  A hit that
@@ -1541,7 +1554,13 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
             const float keep = (seeThrough && tr < 1.0f) ? tr : 1.0f;
             const f3 own = thr * keep;
             float* a3 = acc + 3ull * sample;
-            if (!black) {
+            const bool sendsOn = !black && (rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f);
+            if (MODE == 2) {
+                /* the light of a hit that sends on a reflection ray is parked beside the ks the other half parked */
+                float* c6 = chain + ((size_t)depth * rp.n_samples + sample) * 6;
+                float* dst = sendsOn ? c6 : a3;
+                dst[0] = Lo.x, dst[1] = Lo.y, dst[2] = Lo.z;
+            } else if (MODE == 0 && !black) {
                 if (depth == 0) {
                     a3[0] = keep * Lo.x, a3[1] = keep * Lo.y, a3[2] = keep * Lo.z;
                 } else if (!seeThrough) {
@@ -1554,7 +1573,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
                     atomicAdd(a3 + 2, own.z * Lo.z);
                 }
             }
-            if (!black && (rp.features & SRT_F_RECURSIVE) && depth < rp.max_depth && !(sf.ks.x == 0.0f && sf.ks.y == 0.0f && sf.ks.z == 0.0f)) {
+            if (MODE != 2 && sendsOn) {
                 /* computeReflectionRay, reference src/shading.cpp:33-51; offset = float(pow(10, -5)) */
                 const float offset = 9.99999975e-06f;
                 const f3 dn = normalize3(d);
@@ -1565,12 +1584,14 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
                 spawn = true;
                 if (!seeThrough) {
                     float* c6 = chain + ((size_t)depth * rp.n_samples + sample) * 6;
-                    c6[0] = Lo.x, c6[1] = Lo.y, c6[2] = Lo.z, c6[3] = sf.ks.x, c6[4] = sf.ks.y, c6[5] = sf.ks.z;
+                    if (MODE == 0)
+                        c6[0] = Lo.x, c6[1] = Lo.y, c6[2] = Lo.z;
+                    c6[3] = sf.ks.x, c6[4] = sf.ks.y, c6[5] = sf.ks.z;
                     nlev[sample] = (unsigned char)(depth + 1);
                     a3[0] = a3[1] = a3[2] = 0.0f;
                 }
             }
-            if (!black && seeThrough && tr < 1.0f) {
+            if (MODE == 0 && !black && seeThrough && tr < 1.0f) {
                 /* the ray continued behind the surface, reference src/render.cpp:113 */
                 to = o + d * (0.000001f + T);
                 td = d;
@@ -1578,6 +1599,8 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_shade(SceneDev sc, RenderDev rp, 
                 through = true;
             }
         }
+        if (MODE == 2)
+            continue; /* no successor rays from this half (wave-uniform: every lane takes it) */
         const uint32_t q = queue_slot(spawn, next_count);
         if (spawn) {
             next_paths[3ull * q] = make_float4(ro.x, ro.y, ro.z, rd.x);
@@ -1838,6 +1861,7 @@ struct DevBuf {
 };
 
 #define SRT_MAX_EVENTS 8192
+#define SRT_MAX_SYNC 34 /* one per recursion depth (max_depth <= 30) and a few to spare */
 #define SRT_FAMILIES SRT_KERNEL_FAMILIES /* 0 primary trace, 1 secondary trace, 2 shade, 3 resolve, 4 shadow trace */
 
 /* ---- work memory of the entry point that allocates nothing (srt_render_noalloc).
@@ -1857,10 +1881,15 @@ struct srt_device {
     uint32_t* qcounts = nullptr; /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
     unsigned long long* chunk_counters = nullptr; /* 64: next unclaimed shadow item [0..31] and path ray [32..63] of each depth */
     DevBuf acc, chain, nlev, hq_slot, hq_t, hq_tri, hq_ip, vis, path[2], out_rgb, out_mesh, out_tri, out_t, io_a, io_b;
-    hipEvent_t ev[SRT_MAX_EVENTS];
-    int ev_kind[SRT_MAX_EVENTS]; /* kernel family of the interval that STARTS at event i, -1 for none */
+    hipEvent_t ev[SRT_MAX_EVENTS]; /* timing: events 2 i and 2 i + 1 bracket launch i */
+    int ev_kind[SRT_MAX_EVENTS / 2]; /* kernel family of launch i */
     int n_ev = 0;
     bool ev_ready = false;
+    /* the second stream a short frame's light stage runs on, and the events that order the two (render_impl) */
+    hipStream_t aux = nullptr;
+    hipEvent_t sync_hit[SRT_MAX_SYNC], sync_lit[SRT_MAX_SYNC];
+    bool sync_ready = false;
+    DevBuf hq2_slot, hq2_t, hq2_tri, hq2_ip; /* the second hit queue such a frame alternates with the first */
 };
 
 /* Persistent-grid sizes (blocks that fit the GPU at once) of the four queue kernels. */
@@ -1970,10 +1999,11 @@ int srt_device_create(int gpu_id, srt_device** out)
         }
     }
     hipError_t e = hipMalloc((void**)&d->counters, (SRT_FAMILIES + 1) * sizeof(DevCounters));
+    /* queue counts and chunk counters in one piece: a frame clears them with one memset */
     if (e == hipSuccess)
-        e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t));
+        e = hipMalloc((void**)&d->qcounts, 64 * sizeof(uint32_t) + 64 * sizeof(unsigned long long));
     if (e == hipSuccess)
-        e = hipMalloc((void**)&d->chunk_counters, 64 * sizeof(unsigned long long));
+        d->chunk_counters = (unsigned long long*)(d->qcounts + 64);
     if (e == hipSuccess)
         e = hipMemset(d->counters, 0, (SRT_FAMILIES + 1) * sizeof(DevCounters));
     if (e != hipSuccess) {
@@ -1991,18 +2021,23 @@ void srt_device_destroy(srt_device* d)
     (void)hipSetDevice(d->gpu);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = { &d->acc, &d->chain, &d->nlev, &d->hq_slot, &d->hq_t, &d->hq_tri, &d->hq_ip, &d->vis, &d->path[0], &d->path[1], &d->out_rgb, &d->out_mesh, &d->out_tri,
-        &d->out_t, &d->io_a, &d->io_b };
+        &d->out_t, &d->io_a, &d->io_b, &d->hq2_slot, &d->hq2_t, &d->hq2_tri, &d->hq2_ip };
     for (DevBuf* b : bufs)
         b->release();
     if (d->counters)
         (void)hipFree(d->counters);
     if (d->qcounts)
-        (void)hipFree(d->qcounts);
-    if (d->chunk_counters)
-        (void)hipFree(d->chunk_counters);
+        (void)hipFree(d->qcounts); /* the chunk counters are part of it */
     if (d->ev_ready)
         for (int i = 0; i < SRT_MAX_EVENTS; ++i)
             (void)hipEventDestroy(d->ev[i]);
+    if (d->sync_ready)
+        for (int i = 0; i < SRT_MAX_SYNC; ++i) {
+            (void)hipEventDestroy(d->sync_hit[i]);
+            (void)hipEventDestroy(d->sync_lit[i]);
+        }
+    if (d->aux)
+        (void)hipStreamDestroy(d->aux);
     delete d;
 }
 
@@ -2064,16 +2099,12 @@ int srt_device_kernel_times(srt_device* d, float ms[SRT_KERNEL_FAMILIES], int32_
     HIPCHK(hipSetDevice(d->gpu));
     for (int k = 0; k < SRT_FAMILIES; ++k)
         ms[k] = 0.0f, launches[k] = 0;
-    if (d->n_ev >= 2) {
-        HIPCHK(hipEventSynchronize(d->ev[d->n_ev - 1]));
-        for (int i = 0; i + 1 < d->n_ev; ++i) {
-            if (d->ev_kind[i] < 0)
-                continue;
-            float t = 0;
-            HIPCHK(hipEventElapsedTime(&t, d->ev[i], d->ev[i + 1]));
-            ms[d->ev_kind[i]] += t;
-            launches[d->ev_kind[i]] += 1;
-        }
+    for (int i = 0; 2 * i + 1 < d->n_ev; ++i) {
+        float t = 0;
+        HIPCHK(hipEventSynchronize(d->ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&t, d->ev[2 * i], d->ev[2 * i + 1]));
+        ms[d->ev_kind[i]] += t;
+        launches[d->ev_kind[i]] += 1;
     }
     if (reset)
         d->n_ev = 0;
@@ -2270,24 +2301,30 @@ static int persistent_grid(srt_device* d, K kernel, size_t lds, int* grid, int b
     return SRT_OK;
 }
 
-/* Records one event of the timing ring; the interval that starts at it belongs to kernel family `kind`
- * (-1 closes a call's last interval).  When the ring is full, further launches are simply not timed. */
-static void mark(srt_device* d, hipStream_t st, int kind, bool timing)
+/* Timing of one launch: tick() before it and tock() after it record a pair of events on the launch's stream; the pair
+ * belongs to kernel family `kind`.  When the ring is full, further launches are simply not timed. */
+static bool tick(srt_device* d, hipStream_t st, int kind, bool timing)
 {
     if (!timing)
-        return;
+        return false;
     if (!d->ev_ready) {
         for (int i = 0; i < SRT_MAX_EVENTS; ++i)
             if (hipEventCreate(&d->ev[i]) != hipSuccess)
-                return;
+                return false;
         d->ev_ready = true;
     }
-    /* keep room for a closing event so that an interval never runs into the next call */
-    if (d->n_ev >= SRT_MAX_EVENTS - (kind >= 0 ? 1 : 0))
-        return;
+    if (d->n_ev + 2 > SRT_MAX_EVENTS)
+        return false;
     (void)hipEventRecord(d->ev[d->n_ev], st);
-    d->ev_kind[d->n_ev] = kind;
-    d->n_ev += 1;
+    d->ev_kind[d->n_ev / 2] = kind;
+    return true;
+}
+static void tock(srt_device* d, hipStream_t st, bool ticked)
+{
+    if (!ticked)
+        return;
+    (void)hipEventRecord(d->ev[d->n_ev + 1], st);
+    d->n_ev += 2;
 }
 
 /* Shadow queries per hit: the same count the kernels derive from the light list (shadow_samples). */
@@ -2308,6 +2345,7 @@ struct Work {
     float* chain = nullptr;          /* reflections without transparency: 6 floats per (level < max_depth, sample), see k_shade */
     unsigned char* nlev = nullptr;   /* ... and the number of levels a sample has parked there */
     HitQ hq {};                      /* one entry per sample (more with transparency) */
+    HitQ hq2 {};                     /* optional second hit queue: lets a short frame overlap its light stage with the next depth's trace */
     unsigned char* vis = nullptr;    /* one byte per (hit, shadow query) */
     float4* path[2] = { nullptr, nullptr }; /* 3 float4 per queued path ray; only with reflections / transparency */
     uint32_t* qcounts = nullptr;     /* 64 words: hit-queue counts [0..31], path-queue counts [32..63] */
@@ -2341,45 +2379,126 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     uint32_t* path_count = wk.qcounts + 32;
     float* acc = wk.acc;
     unsigned char* vis = wk.vis;
-    HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
-    HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 64 * sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(acc, 0, (size_t)n * 3 * sizeof(float), st));
+    /* the only buffers a frame needs cleared: queue counts and chunk counters (contiguous where the handle owns them) */
+    if ((void*)wk.chunk_counters == (void*)(wk.qcounts + 64)) {
+        HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t) + 64 * sizeof(unsigned long long), st));
+    } else {
+        HIPCHK(hipMemsetAsync(wk.qcounts, 0, 64 * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(wk.chunk_counters, 0, 64 * sizeof(unsigned long long), st));
+    }
     const bool chained = (rp.features & SRT_F_RECURSIVE) && !(rp.features & SRT_F_TRANSPARENCY) && rp.max_depth > 0;
     float* chain = chained ? wk.chain : nullptr;
     unsigned char* nlev = chained ? wk.nlev : nullptr;
-    if (chained) {
-        if (!chain || !nlev)
-            return fail(SRT_ERR_INVALID, "reflections need the per-level buffers");
-        HIPCHK(hipMemsetAsync(nlev, 0, n, st));
-    }
+    if (chained && (!chain || !nlev))
+        return fail(SRT_ERR_INVALID, "reflections need the per-level buffers");
+    const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
+    int g_res = (int)((n_px + SRT_BLOCK - 1) / SRT_BLOCK);
+    if (g_res > d->n_cu * 8) g_res = d->n_cu * 8;
     if (rp.lens_mode && rp.lens.samples == 0) {
-        /* motion blur / depth of field with zero samples: the reference's loops do not run and the pixel stays black */
-        const uint32_t npx = (uint32_t)rp.tw * (uint32_t)rp.th;
-        int gr = (int)((npx + SRT_BLOCK - 1) / SRT_BLOCK);
-        if (gr > d->n_cu * 8) gr = d->n_cu * 8;
-        hipLaunchKernelGGL(k_resolve, dim3(gr), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
+        /* motion blur / depth of field with zero samples: the reference's loops do not run and the pixel stays black
+         * (k_resolve reads no sample slot then) */
+        hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
         HIPCHK(hipGetLastError());
         return SRT_OK;
     }
-    mark(d, st, 0, timing);
-    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0, acc);
+    auto launch_shadow = [&](hipStream_t s, int depth, const HitQ& q, const float4* cur) {
+        if (!sph)
+            return;
+        const bool t = tick(d, s, 4, timing);
+        if (coarse)
+            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, CULL>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), s, sc->view, rp, depth, q,
+                hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
+        else
+            hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, false>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), s, sc->view, rp, depth, q,
+                hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
+        tock(d, s, t);
+    };
+    auto launch_secondary = [&](hipStream_t s, int depth, const HitQ& q, const float4* rays) {
+        /* Rays fed like shadow queries (chunks + lane refill) once a rectangle is large: dragon stand-in 7680x4320, 64
+         * samples per pixel in 960x540 rectangles 223.6 -> 195.9 ms per frame (box steps at 45 instead of 34 lanes), but monkey
+         * 1920x1080, whose launches hold a few rays per lane, 0.674 -> 0.905 ms.  SRT_SECONDARY_REFILL=0 / 1 forces the choice
+         * (tests run both kernels at every size). */
+        static const char* refill_env = getenv("SRT_SECONDARY_REFILL");
+        const bool refill = refill_env ? refill_env[0] == '1' : rp.n_samples >= (1u << 24);
+        const bool t = tick(d, s, 1, timing);
+        if (refill && (rp.features & SRT_F_ACCEL))
+            hipLaunchKernelGGL((k_trace_secondary_refill<CULL, COUNT>), dim3(need < g.secondary_refill ? need : g.secondary_refill), dim3(SRT_BLOCK), lds, s,
+                sc->view, rp.features, rays, path_count + depth + 1, q, hq_count + depth + 1, d->counters + 1, acc, wk.chunk_counters + 32 + depth);
+        else
+            hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, s, sc->view, rp.features, rays,
+                path_count + depth + 1, q, hq_count + depth + 1, d->counters + 1, acc);
+        tock(d, s, t);
+    };
+    bool t = tick(d, st, 0, timing);
+    hipLaunchKernelGGL((k_trace_primary<CULL, COUNT>), dim3(g_primary), dim3(SRT_BLOCK), lds, st, sc->view, rp, hq, hq_count, d->counters + 0, acc, nlev);
+    tock(d, st, t);
     const bool branching = (rp.features & SRT_F_TRANSPARENCY) != 0;
     const int last_depth = (rp.features & (SRT_F_RECURSIVE | SRT_F_TRANSPARENCY)) ? rp.max_depth : 0;
+
+    /* ---- short frames with reflections: two streams.
+     * A hit's reflection ray does not depend on its light, only the sample's value does.  The depth loop is therefore
+     * cut in two chains: on the caller's stream  primary, [send on, trace]_1, [send on, trace]_2 ...  (k_shade<1>,
+     * k_trace_secondary) and, one stage behind on a stream of the handle's own,  [shadow, light]_0, [shadow, light]_1 ...
+     * (k_trace_shadow, k_shade<2>).  The launches of a 1920 x 1080 frame are short and leave most of the GPU idle, so the
+     * two chains run side by side and the frame takes the longer one instead of their sum.  Depths alternate between two
+     * hit queues; an event per depth keeps a queue (and the ray buffer of the same parity) from being overwritten before
+     * its light stage has read it.  Large rectangles fill the GPU with either chain alone and keep the single stream. */
+    /* (Measured at 1920 x 1080: monkey, 11 levels, 1.35 -> 1.11 ms per frame; the textured cube, 5 levels, whose launches
+     * are all but empty, 0.33 -> 0.39 ms: there the cross-stream waits cost more than the overlap saves, hence the
+     * condition on the tree's depth.  SRT_OVERLAP=0 / 1 forces the choice; the parity tests run both.) */
+    static const char* overlap_env = getenv("SRT_OVERLAP");
+    const bool small = overlap_env ? overlap_env[0] == '1' : (rp.n_samples < (1u << 23) && sc->num_levels >= 8);
+    if (chained && small && wk.hq2.slot && last_depth > 0 && last_depth < SRT_MAX_SYNC - 1) {
+        if (!d->sync_ready) {
+            HIPCHK(hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking));
+            for (int i = 0; i < SRT_MAX_SYNC; ++i) {
+                HIPCHK(hipEventCreateWithFlags(&d->sync_hit[i], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&d->sync_lit[i], hipEventDisableTiming));
+            }
+            d->sync_ready = true;
+        }
+        hipStream_t sb = d->aux;
+        const HitQ q2[2] = { wk.hq, wk.hq2 };
+        HIPCHK(hipEventRecord(d->sync_hit[0], st)); /* hits of depth 0 queued (and everything the caller enqueued before) */
+        for (int depth = 0; depth <= last_depth; ++depth) {
+            const float4* cur = wk.path[depth & 1];
+            float4* nxt = wk.path[(depth + 1) & 1];
+            if (depth < last_depth) {
+                /* the rays this stage writes replace those of depth - 1, and the next trace fills the hit queue of
+                 * depth - 1: both are read by that depth's light stage */
+                if (depth >= 1)
+                    HIPCHK(hipStreamWaitEvent(st, d->sync_lit[depth - 1], 0));
+                t = tick(d, st, 2, timing);
+                hipLaunchKernelGGL(k_shade<1>, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, q2[depth & 1], hq_count + depth, cur, nxt,
+                    path_count + depth + 1, acc, chain, nlev, (const unsigned char*)vis, sph, d->counters + 2);
+                tock(d, st, t);
+                launch_secondary(st, depth, q2[(depth + 1) & 1], (const float4*)nxt);
+                HIPCHK(hipEventRecord(d->sync_hit[depth + 1], st));
+            }
+            HIPCHK(hipStreamWaitEvent(sb, d->sync_hit[depth], 0));
+            launch_shadow(sb, depth, q2[depth & 1], cur);
+            t = tick(d, sb, 2, timing);
+            hipLaunchKernelGGL(k_shade<2>, dim3(g_shade), dim3(SRT_BLOCK), 0, sb, sc->view, rp, depth, q2[depth & 1], hq_count + depth, cur, nxt,
+                path_count + depth + 1, acc, chain, nlev, (const unsigned char*)vis, sph, d->counters + 2);
+            tock(d, sb, t);
+            HIPCHK(hipEventRecord(d->sync_lit[depth], sb));
+        }
+        HIPCHK(hipStreamWaitEvent(st, d->sync_lit[last_depth], 0)); /* the second stream runs in order: all its stages are done */
+        t = tick(d, st, 3, timing);
+        hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
+        tock(d, st, t);
+        HIPCHK(hipGetLastError());
+        return SRT_OK;
+    }
+
     for (int depth = 0; depth <= last_depth; ++depth) {
         const float4* cur = wk.path[depth & 1];
         float4* nxt = wk.path[(depth + 1) & 1];
-        if (sph) {
-            mark(d, st, 4, timing);
-            if (coarse)
-                hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, CULL>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq,
-                    hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
-            else
-                hipLaunchKernelGGL((k_trace_shadow<CULL, COUNT, false>), dim3(g_shadow), dim3(SRT_SHADOW_BLOCK), shadow_lds_bytes(sc), st, sc->view, rp, depth, hq,
-                    hq_count + depth, cur, vis, sph, d->counters + 4, wk.chunk_counters + depth);
-        }
-        mark(d, st, 2, timing);
-        hipLaunchKernelGGL(k_shade, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
+        launch_shadow(st, depth, hq, cur);
+        t = tick(d, st, 2, timing);
+        hipLaunchKernelGGL(k_shade<0>, dim3(g_shade), dim3(SRT_BLOCK), 0, st, sc->view, rp, depth, hq, hq_count + depth, cur, nxt, path_count + depth + 1,
             acc, chain, nlev, (const unsigned char*)vis, sph, d->counters + 2);
+        tock(d, st, t);
         if (depth == last_depth)
             break;
         if (branching) {
@@ -2408,26 +2527,11 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
             vis = (unsigned char*)d->vis.p;
             wk.path[depth & 1] = (float4*)d->path[depth & 1].p;
         }
-        mark(d, st, 1, timing);
-        /* Rays fed like shadow queries (chunks + lane refill) once a rectangle is large: dragon stand-in 7680x4320, 64
-         * samples per pixel in 960x540 rectangles 223.6 -> 195.9 ms per frame (box steps at 45 instead of 34 lanes), but monkey
-         * 1920x1080, whose launches hold a few rays per lane, 0.674 -> 0.905 ms.  SRT_SECONDARY_REFILL=0 / 1 forces the choice
-         * (tests run both kernels at every size). */
-        static const char* refill_env = getenv("SRT_SECONDARY_REFILL");
-        const bool refill = refill_env ? refill_env[0] == '1' : rp.n_samples >= (1u << 24);
-        if (refill && (rp.features & SRT_F_ACCEL))
-            hipLaunchKernelGGL((k_trace_secondary_refill<CULL, COUNT>), dim3(need < g.secondary_refill ? need : g.secondary_refill), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
-                path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc, wk.chunk_counters + 32 + depth);
-        else
-        hipLaunchKernelGGL((k_trace_secondary<CULL, COUNT>), dim3(g_secondary), dim3(SRT_BLOCK), lds, st, sc->view, rp.features, (const float4*)nxt,
-            path_count + depth + 1, hq, hq_count + depth + 1, d->counters + 1, acc);
+        launch_secondary(st, depth, hq, (const float4*)nxt);
     }
-    mark(d, st, 3, timing);
-    const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
-    int g_res = (int)((n_px + SRT_BLOCK - 1) / SRT_BLOCK);
-    if (g_res > d->n_cu * 8) g_res = d->n_cu * 8;
+    t = tick(d, st, 3, timing);
     hipLaunchKernelGGL(k_resolve, dim3(g_res), dim3(SRT_BLOCK), 0, st, rp, (const float*)acc, (const float*)chain, (const unsigned char*)nlev);
-    mark(d, st, -1, timing);
+    tock(d, st, t);
     HIPCHK(hipGetLastError());
     return SRT_OK;
 }
@@ -2441,7 +2545,7 @@ static int fill_grids(srt_device* d, srt_scene* sc)
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_secondary_refill<CULL, COUNT>, stack_bytes(sc), &g.secondary_refill);
     if (rc == SRT_OK) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, false>, shadow_lds_bytes(sc), &g.shadow, SRT_SHADOW_BLOCK);
     if (rc == SRT_OK && CULL) rc = persistent_grid(d, k_trace_shadow<CULL, COUNT, true>, shadow_lds_bytes(sc), &g.shadow_coarse, SRT_SHADOW_BLOCK);
-    if (rc == SRT_OK) rc = persistent_grid(d, k_shade, 0, &g.shade);
+    if (rc == SRT_OK) rc = persistent_grid(d, k_shade<0>, 0, &g.shade);
     return rc;
 }
 
@@ -2568,12 +2672,23 @@ static int handle_work(srt_device* d, srt_scene* sc, uint32_t n, uint32_t featur
         rc = d->path[0].reserve((size_t)n * per);
         if (rc == SRT_OK) rc = d->path[1].reserve((size_t)n * per);
     }
+    bool second = false;
     if (rc == SRT_OK && (features & SRT_F_RECURSIVE) && !(features & SRT_F_TRANSPARENCY) && max_depth > 0) {
         rc = d->chain.reserve((size_t)n * 24 * (size_t)max_depth);
         if (rc == SRT_OK) rc = d->nlev.reserve(n);
+        /* frames short enough to overlap their two chains of launches (render_impl) get a second hit queue */
+        if (rc == SRT_OK && n < (1u << 23)) {
+            rc = d->hq2_slot.reserve((size_t)n * 4);
+            if (rc == SRT_OK) rc = d->hq2_t.reserve((size_t)n * 4);
+            if (rc == SRT_OK) rc = d->hq2_tri.reserve((size_t)n * 4);
+            if (rc == SRT_OK) rc = d->hq2_ip.reserve((size_t)n * 16);
+            second = rc == SRT_OK;
+        }
     }
     if (rc != SRT_OK)
         return rc;
+    if (second)
+        wk->hq2 = { (uint32_t*)d->hq2_slot.p, (float*)d->hq2_t.p, (uint32_t*)d->hq2_tri.p, (float4*)d->hq2_ip.p };
     wk->acc = (float*)d->acc.p;
     wk->chain = (float*)d->chain.p, wk->nlev = (unsigned char*)d->nlev.p;
     wk->hq = { (uint32_t*)d->hq_slot.p, (float*)d->hq_t.p, (uint32_t*)d->hq_tri.p, (float4*)d->hq_ip.p };

@@ -1,7 +1,9 @@
-"""The reflection-ray kernel exists twice: with a fixed stride over the path queue (small rectangles) and fed like the
-shadow kernel, in chunks with lane refill (rectangles of 2^24 samples and more).  SRT_SECONDARY_REFILL forces the choice;
-here the parity tests that send on reflection, transmission and environment rays run once more in a child process with the
-refill kernel forced at their small sizes."""
+"""Two choices the render loop makes by the size of a rectangle, each forced the other way here and the parity tests that
+send on reflection, transmission and environment rays run once more in a child process.
+The reflection-ray kernel exists twice: with a fixed stride over the path queue (small rectangles) and fed like the shadow
+kernel, in chunks with lane refill (rectangles of 2^24 samples and more): SRT_SECONDARY_REFILL.
+A frame with reflections runs its launches on one stream, or - short frames of deep trees - as two chains on two streams,
+the light stages beside the next depth's trace: SRT_OVERLAP."""
 import os
 import subprocess
 import sys
@@ -17,5 +19,16 @@ def test_parity_with_the_refill_kernel_forced():
     r = subprocess.run([sys.executable, "-u", "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_random_scenes.py"),
                         "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "150", "--timeout-method", "thread", "-k",
                         "recursive or reflection or transparency or environment or render_matches or random_scenes or final_color or tiles"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_parity_with_the_two_stream_frame_forced(overlap):
+    env = dict(os.environ, SRT_OVERLAP=overlap)
+    r = subprocess.run([sys.executable, "-u", "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_random_scenes.py"),
+                        "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "150", "--timeout-method", "thread", "-k",
+                        "recursive or reflection or environment or render_matches or random_scenes or final_color or tiles or multisample or dragon_standin_frame"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

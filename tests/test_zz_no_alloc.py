@@ -112,3 +112,4 @@ def test_noalloc_allocates_nothing():
     bvh.render_device(bvh.params(cam4k, feat, 2, 2, 5, 0, None, 0), big.data_ptr(), 3840, 2160, 0, 0, stream)
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] < free0  # the allocating entry point grew the handle's work buffers
+
