@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dragon", choices=["dragon", "dragon8k", "teapot", "monkey", "cube_textured"])
-    ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU, 480x270 otherwise; 960x540 for dragon8k)")
+    ap.add_argument("--tile", type=int, nargs=2, default=None, help="tile width height (default: whole frame on 1 GPU; a 4 x 4, 8 x 4 or 8 x 8 grid of tiles for 2, up to 4, more ranks; 960x540 for dragon8k)")
     ap.add_argument("--profile-summary", default=None, help="rocprofv3 --pmc summary (profiles/summarize.py output) to take the fabric-side "
                     "traffic and cache counters from; default: the newest profiles/*_summary.txt taken with the current kernel sources")
     ap.add_argument("--dragon-obj", default=None, help="OBJ file of the real dragon (absent from the reference checkout) to render instead of the "
@@ -272,6 +272,7 @@ def main():
                     "tell about the fixed per-frame cost of N ranks")
     ap.add_argument("--lanes", type=int, default=None, help="back-end contexts (each with its stream) a tiled frame alternates between "
                     "(default 2; 1 for dragon8k, whose rectangles are large enough for their tails not to matter)")
+    ap.add_argument("--in-flight", type=int, default=None, help="tiles a rank may have enqueued and unfinished (default: one per lane)")
     args = ap.parse_args()
 
     import torch
@@ -314,7 +315,10 @@ def main():
     cam = srt.make_camera(W, H)
 
     tiling = importlib.import_module("simple-ray-tracer_amd.distributed")
-    tw, th = args.tile if args.tile else (cfg["tile"] if cfg["tile"] else ((W, H) if (world == 1 and not probe) else (480, 270)))
+    # Tiles per rank: enough of them for stealing to even out the ranks (about eight each), no more, because a frame in 64
+    # tiles costs 7 % more GPU time than the same frame in one piece and one in 16 tiles 2 % (4K dragon frame, one GPU).
+    by_world = (W, H) if (world == 1 and not probe) else ((W // 4, H // 4) if world <= 2 and not probe else ((W // 8, H // 4) if world <= 4 and not probe else (W // 8, H // 8)))
+    tw, th = args.tile if args.tile else (cfg["tile"] if cfg["tile"] else by_world)
     counter = board = None
     if world > 1 or probe:
         name = f"/srt_tiles_{os.environ.get('MASTER_PORT', '0')}"
@@ -326,14 +330,18 @@ def main():
         if rank != 0:
             counter = srt.TileCounter(name, False)
             board = srt.FrameBoard(name + "_board", False, world, n_rects)
-    tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter, board=board)
+    n_lanes = max(1, args.lanes if args.lanes is not None else cfg.get("lanes", 2))
+    tiler = tiling.FrameTiler(W, H, tw, th, dev, rank, world, counter, board=board, max_in_flight=args.in_flight if args.in_flight else max(2, n_lanes))
     gather_parts = []
     n_tiles = tiler.n_tiles
     # A frame cut into tiles alternates between two back-end contexts on two streams, so that the tail of one
     # tile's kernels overlaps the start of the next tile's (a context owns its work buffers and scene copy).
     lanes = [(bvh, torch.cuda.current_stream())]
     if n_tiles > 1:
-        for ctx in range(1, max(1, args.lanes if args.lanes is not None else cfg.get("lanes", 2))):
+        # every lane on a stream of its own: launches on the default stream were measured not to run beside those of
+        # another lane at all (64 tiles: 125.1 ms per frame with lane 0 on the default stream, 118.5 ms without)
+        lanes = [(bvh, torch.cuda.Stream())]
+        for ctx in range(1, n_lanes):
             srt.set_device(local_rank, context=ctx)
             lanes.append((srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL), torch.cuda.Stream()))
         srt.set_device(local_rank, context=0)

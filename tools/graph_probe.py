@@ -1,6 +1,9 @@
 """Does replaying a frame's launches as one HIP graph help a launch-bound frame?  srt_render_noalloc (allocation free,
 stream ordered) is captured on a torch stream and replayed; compared with calling it directly.  usage (GPU box):
-python3 tools/graph_probe.py"""
+python3 tools/graph_probe.py
+Run it in a process of its own.  The same capture at the end of a test process that had rendered with several handles
+before ended with a GPU fault whose cause was not established (capture and replay are PyTorch's and the HIP runtime's;
+the library only sees stream-ordered calls), which is why no test captures a graph."""
 import importlib, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

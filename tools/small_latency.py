@@ -10,6 +10,11 @@ for wl in ("teapot", "monkey", "cube_textured"):
     W, H = cfg["width"], cfg["height"]
     cam = srt.make_camera(W, H)
     buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    # SRT_LATENCY_STREAM=pool: a stream of PyTorch's pool instead of the default stream (which hardware queue a stream
+    # lands on decides whether the handle's second stream can run beside it)
+    own = torch.cuda.Stream() if os.environ.get("SRT_LATENCY_STREAM") == "pool" else None
+    if own is not None:
+        torch.cuda.set_stream(own)
     st = torch.cuda.current_stream().cuda_stream
     for flags, what in ((0, "plain"), (srt.RENDER_TIMING, "timing events")):
         p = bvh.params(cam, cfg["features"], cfg["nsx"], cfg["nsy"], cfg["max_depth"], 0, None, flags)
