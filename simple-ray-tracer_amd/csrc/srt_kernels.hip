@@ -1888,6 +1888,7 @@ struct srt_device {
     /* the second stream a short frame's light stage runs on, and the events that order the two (render_impl) */
     hipStream_t aux = nullptr;
     hipEvent_t sync_hit[SRT_MAX_SYNC], sync_lit[SRT_MAX_SYNC];
+    int sync_made = 0; /* event pairs created so far */
     bool sync_ready = false;
     DevBuf hq2_slot, hq2_t, hq2_tri, hq2_ip; /* the second hit queue such a frame alternates with the first */
 };
@@ -2031,11 +2032,10 @@ void srt_device_destroy(srt_device* d)
     if (d->ev_ready)
         for (int i = 0; i < SRT_MAX_EVENTS; ++i)
             (void)hipEventDestroy(d->ev[i]);
-    if (d->sync_ready)
-        for (int i = 0; i < SRT_MAX_SYNC; ++i) {
-            (void)hipEventDestroy(d->sync_hit[i]);
-            (void)hipEventDestroy(d->sync_lit[i]);
-        }
+    for (int i = 0; i < d->sync_made; ++i) {
+        (void)hipEventDestroy(d->sync_hit[i]);
+        (void)hipEventDestroy(d->sync_lit[i]);
+    }
     if (d->aux)
         (void)hipStreamDestroy(d->aux);
     delete d;
@@ -2450,10 +2450,14 @@ static int render_impl(srt_device* d, srt_scene* sc, const RenderDev& rp, uint32
     const bool small = overlap_env ? overlap_env[0] == '1' : (rp.n_samples < (1u << 23) && sc->num_levels >= 8);
     if (chained && small && wk.hq2.slot && last_depth > 0 && last_depth < SRT_MAX_SYNC - 1) {
         if (!d->sync_ready) {
-            HIPCHK(hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking));
-            for (int i = 0; i < SRT_MAX_SYNC; ++i) {
-                HIPCHK(hipEventCreateWithFlags(&d->sync_hit[i], hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&d->sync_lit[i], hipEventDisableTiming));
+            if (!d->aux)
+                HIPCHK(hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking));
+            for (; d->sync_made < SRT_MAX_SYNC; ++d->sync_made) {
+                HIPCHK(hipEventCreateWithFlags(&d->sync_hit[d->sync_made], hipEventDisableTiming));
+                if (hipEventCreateWithFlags(&d->sync_lit[d->sync_made], hipEventDisableTiming) != hipSuccess) {
+                    (void)hipEventDestroy(d->sync_hit[d->sync_made]);
+                    return fail(SRT_ERR_HIP, "hipEventCreateWithFlags failed (second stream of a short frame)");
+                }
             }
             d->sync_ready = true;
         }
