@@ -143,6 +143,34 @@ SRT_DI void flush_counters(DevCounters* c, uint32_t path, uint32_t shadow, uint3
     }
 }
 
+/* Records of the traversal arrays by 32-bit byte offset from the array's base: the base is wave-uniform (a kernel
+ * argument), so the load takes it from scalar registers and the lane supplies one shifted index, where 64-bit pointer
+ * arithmetic costs the lane a 64-bit shift and a 64-bit add per visit (dragon shadow launch 98.4 -> 96.7 ms).  The
+ * arrays stay below 4 GiB: at most 2^24 triangles of 96 bytes, fewer than 2^25 nodes of 64 bytes (srt_scene_upload
+ * checks).  The empty asm keeps the offset a 32-bit value of its own where a loop would otherwise turn it into a
+ * 64-bit induction pointer. */
+SRT_DI const float4* node_record(const SceneDev& sc, uint32_t i)
+{
+    uint32_t off = i << 6;
+    asm volatile("" : "+v"(off));
+    return (const float4*)((const char*)sc.nodes + off);
+}
+SRT_DI const uint4* wide_record(const SceneDev& sc, uint32_t i)
+{
+    uint32_t off = i << 6;
+    asm volatile("" : "+v"(off));
+    return (const uint4*)((const char*)sc.wnodes + off);
+}
+SRT_DI const float4* tri_record(const SceneDev& sc, uint32_t i)
+{
+    uint32_t off = i * 96u;
+    asm volatile("" : "+v"(off));
+    return (const float4*)((const char*)sc.tris + off);
+}
+/* Lane mask of a predicate, straight from the compare (HIP's __ballot takes an int: the predicate would be turned into
+ * 0 / 1 and compared again, two vector instructions per vote). */
+SRT_DI unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 /* The accel-structure-off branch (reference :319-332): every triangle of every mesh, in scene order. */
 template <bool COUNT>
 SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, Stats& st)
@@ -178,6 +206,7 @@ struct Walk {
     float T, C;
     uint32_t cur, hitTri;
     int sp;
+    uint32_t* top; /* shadow walks: the lane's first free stack entry (entries are SRT_SHADOW_BLOCK words apart) */
     bool alive;
 };
 
@@ -222,7 +251,7 @@ SRT_DI void walk_inner(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
         st.inner += 1;
         st.box += 2;
     }
-    const float4* nd = sc.nodes + 4ull * w.cur;
+    const float4* nd = node_record(sc, w.cur);
     const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
     const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
     const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
@@ -257,7 +286,7 @@ SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
-        if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, w.T)) {
+        if (tri_test(tri_record(sc, first + k), w.o, w.d, w.T)) {
             w.C = min_std(w.C, w.T);
             w.hitTri = first + k;
         }
@@ -285,7 +314,7 @@ SRT_DI bool walk_trip(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
 {
     const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
     const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
-    const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
+    const unsigned long long mInner = ballot64(atInner), mLeaf = ballot64(atLeaf);
     if ((mInner | mLeaf) == 0)
         return false;
     if (__popcll(mInner) * SRT_VOTE_INNER_W >= __popcll(mLeaf) * SRT_VOTE_LEAF_W) {
@@ -325,7 +354,7 @@ template <bool CULL, bool COUNT>
 SRT_DI bool traverse(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& hitTri, uint2* stk, Stats& st)
 {
     /* one decision per wave: every lane's operands in the ranges div_by is exact for, or plain division for all */
-    if (__all(ray_in_fast_range(sc, o, d)))
+    if (ballot64(!ray_in_fast_range(sc, o, d)) == 0)
         return traverse_loop<CULL, COUNT, true>(sc, o, d, T, hitTri, stk, st);
     return traverse_loop<CULL, COUNT, false>(sc, o, d, T, hitTri, stk, st);
 }
@@ -651,7 +680,7 @@ SRT_DI f3 environment_color(const SceneDev& sc, f3 o, f3 d, float T)
 /* Appends the lanes with want == true to a queue: one atomic per wave, slots in lane order. */
 SRT_DI uint32_t queue_slot(bool want, uint32_t* count)
 {
-    const unsigned long long mask = __ballot(want);
+    const unsigned long long mask = ballot64(want);
     if (mask == 0)
         return 0;
     const uint32_t lane = threadIdx.x & 63;
@@ -810,7 +839,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary_refill(SceneDev s
     uint32_t item = 0;
     bool busy = false; /* the lane holds a ray: in flight (w.alive) or finished and waiting to be handed in */
     for (;;) {
-        const unsigned long long spare = __ballot(!w.alive);
+        const unsigned long long spare = ballot64(!w.alive);
         if (__popcll(spare) >= SRT_REFILL_MIN) {
             /* hand in what has finished since the last time: one atomic for all of it */
             const bool fin = busy && !w.alive;
@@ -874,7 +903,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary_refill(SceneDev s
         }
         if (!walk_trip<CULL, COUNT, true>(sc, w, stk, st)) {
             /* nothing in flight: every lane is spare, so the next pass hands in and refills, or the wave is done */
-            if (dry && __ballot(busy) == 0)
+            if (dry && ballot64(busy) == 0)
                 break;
         }
     }
@@ -968,7 +997,7 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
             for (uint32_t k = 0; k < cnt; ++k) {
                 if (COUNT)
                     st.tri += 1;
-                if (tri_test(sc.tris + 6ull * (first + k), o, d, T))
+                if (tri_test(tri_record(sc, first + k), o, d, T))
                     C = min_std(C, T);
             }
             if (T < 0.99f && C != SRT_FLT_MAX)
@@ -978,7 +1007,7 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
                 st.inner += 1;
                 st.box += 2;
             }
-            const float4* nd = sc.nodes + 4ull * cur;
+            const float4* nd = node_record(sc, cur);
             const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
             const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
             const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
@@ -1004,7 +1033,7 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
         bool found = false;
         while (sp > 0 && !found) {
             --sp;
-            const float4* nd = sc.nodes + 4ull * stk[sp * SRT_SHADOW_BLOCK];
+            const float4* nd = node_record(sc, stk[sp * SRT_SHADOW_BLOCK]);
             const float4 a = nd[0], b = nd[1];
             const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
             float lval;
@@ -1023,13 +1052,18 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
     }
 }
 
-SRT_DI bool swalk_pop(Walk& w, const uint32_t* stk)
+/* A shadow walk that has ended stands on SRT_WALK_DONE, which no reference equals (as a leaf reference it would pass
+ * 2^24 triangles).  Read as a signed number, `cur >= 0` is an inner node, `cur < -1` a leaf and -1 the ended walk: the
+ * wave's votes are then lane masks straight out of one compare each. */
+#define SRT_WALK_DONE 0xFFFFFFFFu
+SRT_DI void swalk_pop(Walk& w, const uint32_t* stk)
 {
-    if (w.sp == 0)
-        return false;
-    --w.sp;
-    w.cur = stk[w.sp * SRT_SHADOW_BLOCK];
-    return true;
+    if (w.top == stk) {
+        w.cur = SRT_WALK_DONE;
+        return;
+    }
+    w.top -= SRT_SHADOW_BLOCK;
+    w.cur = *w.top;
 }
 
 /* walk_inner with t = 1 and C = FLT_MAX: every value of a box in the fast ranges is finite, so the push test
@@ -1041,7 +1075,7 @@ SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
         st.inner += 1;
         st.box += 2;
     }
-    const float4* nd = sc.nodes + 4ull * w.cur;
+    const float4* nd = node_record(sc, w.cur);
     const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
     const float llo[3] = { a.x, a.y, a.z }, lhi[3] = { a.w, b.x, b.y };
     const float rlo[3] = { b.z, b.w, c.x }, rhi[3] = { c.y, c.z, c.w };
@@ -1051,15 +1085,15 @@ SRT_DI void swalk_inner(const SceneDev& sc, Walk& w, uint32_t* stk, Stats& st)
     const bool pushL = slab_test_fast(llo, lhi, w.o, w.d, w.rr, 1.0f, lval, lin) || !CULL;
     const bool pushR = slab_test_fast(rlo, rhi, w.o, w.d, w.rr, 1.0f, rval, rin) || !CULL;
     if (pushL && pushR) {
-        stk[w.sp * SRT_SHADOW_BLOCK] = left;
-        ++w.sp;
+        *w.top = left;
+        w.top += SRT_SHADOW_BLOCK;
         w.cur = right;
     } else if (pushR) {
         w.cur = right;
     } else if (pushL) {
         w.cur = left;
     } else {
-        w.alive = swalk_pop(w, stk);
+        swalk_pop(w, stk);
     }
 }
 
@@ -1219,33 +1253,39 @@ SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint
         const uint4* nd = top + 4u * w.cur; /* the block's LDS copy of the top levels */
         s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     } else {
-        const uint4* nd = sc.wnodes + 4ull * w.cur;
+        const uint4* nd = wide_record(sc, w.cur);
         s0 = nd[0], s1 = nd[1], s2 = nd[2], s3 = nd[3];
     }
     /* all four slots are tested, without branches: the record's four quarters are requested together (an unused slot
      * fails the test by its box) */
     const bool m0 = coarse_meets(s0, w), m1 = coarse_meets(s1, w), m2 = coarse_meets(s2, w), m3 = coarse_meets(s3, w);
-    const bool p1 = m1 & m0, p2 = m2 & (m0 | m1), p3 = m3 & (m0 | m1 | m2);
+    /* logical operators on the finished tests: the lane masks are then combined in scalar registers (`&` / `|` on bools
+     * are integer operations: the masks would be turned into 0 / 1 values in vector registers, combined there and
+     * compared again, a dozen vector instructions per visit; shadow launch 98.3 -> 95.5 ms) */
+    const bool m01 = m0 || m1, m012 = m01 || m2;
+    const bool p1 = m1 && m0, p2 = m2 && m01, p3 = m3 && m012;
     /* A visit that stacks anything needs room for three entries and one to spare, whatever it stacks: the three stores
      * below are then unconditional (an entry that is not wanted is overwritten by the next store or never read; a visit
      * that stacks nothing stores to the entry above the top, which the spare one guarantees to exist) and the only
      * branch left is this one. */
-    if ((p1 | p2 | p3) & (w.sp + 3 >= (int)sc.wide_cap)) {
-        w.alive = false;
+    uint32_t* t = w.top;
+    if ((p1 || p2 || p3) && (t + 3 * SRT_SHADOW_BLOCK >= stk + sc.wide_cap * SRT_SHADOW_BLOCK)) {
+        w.cur = SRT_WALK_DONE;
         return true;
     }
-    int sp = w.sp;
-    stk[sp * SRT_SHADOW_BLOCK] = s3.w;
-    sp += (int)p3;
-    stk[sp * SRT_SHADOW_BLOCK] = s2.w;
-    sp += (int)p2;
-    stk[sp * SRT_SHADOW_BLOCK] = s1.w;
-    sp += (int)p1;
-    w.sp = sp;
-    if (m0 | m1 | m2 | m3)
+    /* the stack position is kept as the entry's address and moved by selects on the tests' lane masks: the masks are
+     * combined in scalar registers and never become 0 / 1 values in vector ones */
+    *t = s3.w;
+    t = p3 ? t + SRT_SHADOW_BLOCK : t;
+    *t = s2.w;
+    t = p2 ? t + SRT_SHADOW_BLOCK : t;
+    *t = s1.w;
+    t = p1 ? t + SRT_SHADOW_BLOCK : t;
+    w.top = t;
+    if (m012 || m3)
         w.cur = m0 ? s0.w : (m1 ? s1.w : (m2 ? s2.w : s3.w));
     else
-        w.alive = swalk_pop(w, stk);
+        swalk_pop(w, stk);
     return false;
 }
 
@@ -1264,14 +1304,14 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
-        if (tri_test(sc.tris + 6ull * (first + k), w.o, w.d, T))
+        if (tri_test(tri_record(sc, first + k), w.o, w.d, T))
             hit = true;
     }
     if (hit) {
-        w.alive = false;
+        w.cur = SRT_WALK_DONE;
         return T < 0.99f ? 1 : 2;
     }
-    w.alive = swalk_pop(w, stk);
+    swalk_pop(w, stk);
     return 0;
 }
 
@@ -1353,12 +1393,14 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
     uint32_t used = 0; /* items taken from the current chunk */
     Walk w;
     w.alive = false;
-    w.cur = 0, w.sp = 0, w.T = 1.0f, w.C = SRT_FLT_MAX, w.hitTri = 0;
+    w.cur = SRT_WALK_DONE, w.sp = 0, w.top = stk, w.T = 1.0f, w.C = SRT_FLT_MAX, w.hitTri = 0;
     unsigned long long item = 0;
     bool busy = false;
     bool redo = false; /* the lane's query cannot take the common walk */
     for (;;) {
-        const unsigned long long idle = __ballot(!busy);
+        /* at this point a lane is idle exactly when its walk has ended (the answer of an ended walk is handed in at the
+         * bottom of the same trip) */
+        const unsigned long long idle = ballot64(w.cur == SRT_WALK_DONE);
         if (!dry && __popcll(idle) >= SRT_REFILL_MIN && used == chunkItems) {
             chunk = grab();
             locate(chunk);
@@ -1381,6 +1423,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                     hb = hitBase, within = sampleBase + (pos - chunkItems);
                 }
             }
+            bool traced = false;
             if (!busy && mine < n) {
                 item = mine;
                 const uint32_t over = within / shadows_per_hit; /* hits between the chunk's first item and this one */
@@ -1410,21 +1453,24 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                 } else {
                     const f3 dir = pos3 - ip;
                     const f3 org = ip + normalize3(dir) * 0.001f;
-                    nShadow += 1;
+                    traced = true;
                     if (COARSE && (rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
                         /* The walk on the wide records starts without a test of the root box: a ray that misses it
                          * meets none of the root record's slots (or a rounded-out one, and then only finds what the
                          * triangle tests accept), so the test - six exact quotients per query - decides nothing. */
                         w.o = org, w.d = dir, w.T = 1.0f, w.C = SRT_FLT_MAX;
-                        w.cur = sc.root_ref, w.sp = 0, w.alive = true;
+                        w.cur = sc.root_ref, w.top = stk;
                         busy = true;
                         if (!coarse_ray(sc, w))
-                            w.alive = false, redo = true; /* answered by the exact walk below */
+                            w.cur = SRT_WALK_DONE, redo = true; /* answered by the exact walk below */
                     } else if ((rp.features & SRT_F_ACCEL) && ray_in_fast_range(sc, org, dir)) {
                         walk_begin<CULL, COUNT, true>(sc, w, org, dir, 1.0f, st);
+                        w.top = stk;
                         busy = w.alive;
-                        if (!busy)
+                        if (!busy) {
+                            w.cur = SRT_WALK_DONE;
                             vis[item] = 1; /* the ray misses the root box */
+                        }
                     } else {
                         /* An occluded sample is stored as 0 when the shade kernel may skip its Phong term: the direction
                          * to the light has an ordinary length (always so for rays in the ranges of the fast slab test),
@@ -1442,12 +1488,13 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                     }
                 }
             }
+            nShadow += (uint32_t)__builtin_popcountll(ballot64(traced)); /* counted per wave, in a scalar register */
         }
         /* one trip of the wave, as walk_trip: vote, then the kind of step more lanes are waiting for */
-        const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
-        const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
-        const unsigned long long mInner = __ballot(atInner), mLeaf = __ballot(atLeaf);
-        if ((mInner | mLeaf) == 0 && !(COARSE && __any(redo))) {
+        const bool atLeaf = (int)w.cur < -1;
+        const bool atInner = (int)w.cur >= 0;
+        const unsigned long long mInner = ballot64(atInner), mLeaf = ballot64(atLeaf);
+        if ((mInner | mLeaf) == 0 && !(COARSE && ballot64(redo) != 0)) {
             /* nothing in flight: either items remain (every lane is idle, so the next pass refills) or the wave is done */
             if (dry)
                 break;
@@ -1471,9 +1518,9 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
              * six box steps (dragon shadow launch 138.8 -> 119.8 ms; 3 steps 121.5, 17 steps 123.0; thresholds 8 to 24
              * lanes measure the same, 36 lose the gain). */
             for (int rep = 0; rep < SRT_SHADOW_MORE_STEPS; ++rep) {
-                const bool again = atInner && w.alive && !(w.cur & SRT_LEAF_FLAG);
-                const unsigned long long mAgain = __ballot(again);
-                if ((uint32_t)__popcll(mAgain) < SRT_SHADOW_MORE_MIN)
+                const unsigned long long mAgain = ballot64((int)w.cur >= 0) & mInner; /* lanes of this trip's box step still on an inner node */
+                const bool again = atInner && (int)w.cur >= 0;
+                if ((uint32_t)__builtin_popcountll(mAgain) < SRT_SHADOW_MORE_MIN)
                     break;
                 if (COUNT && (int)lane == __ffsll((long long)mAgain) - 1)
                     st.wave_inner += 1;
@@ -1492,7 +1539,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             if (atLeaf)
                 verdict = swalk_leaf<COUNT>(sc, w, stk, st);
         }
-        if (busy && !w.alive) {
+        if (busy && w.cur == SRT_WALK_DONE) {
             if (verdict == 2)
                 vis[item] = shadow_walk_exact<CULL, COUNT, true>(sc, w.o, w.d, stk, st) ? 0 : 1;
             else
@@ -1500,7 +1547,7 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
             busy = false;
         }
     }
-    flush_counters(cnt, 0, nShadow, 0, st);
+    flush_counters(cnt, 0, lane == 0 ? nShadow : 0u, 0, st);
 }
 
 /* getFinalColor for the queued hits of one recursion depth (reference src/render.cpp:96-110).
@@ -2134,6 +2181,8 @@ int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** ou
         return fail(SRT_ERR_INVALID, "scene has %u triangles; the packed child reference addresses at most %u", desc->n_tris, SRT_MAX_TRIS);
     if (desc->num_levels > SRT_MAX_LEVELS)
         return fail(SRT_ERR_INVALID, "BVH has %u levels; the traversal stack supports %d", desc->num_levels, SRT_MAX_LEVELS);
+    if (desc->n_nodes >= (1u << 26))
+        return fail(SRT_ERR_INVALID, "node table has %u records; the kernels address it by 32-bit byte offsets (fewer than 2^26 records)", desc->n_nodes);
     if ((desc->n_nodes && !desc->nodes) || (desc->n_tris && (!desc->tris || !desc->attrs || !desc->scene_order))
         || (desc->n_materials && !desc->materials) || (desc->n_lights && !desc->lights) || (desc->n_textures && (!desc->textures || !desc->texels)))
         return fail(SRT_ERR_INVALID, "srt_scene_upload: a non-empty array is null");

@@ -1,0 +1,449 @@
+/*
+ * sim_beam.cpp -- CPU simulation (development tool, not product code): how many hits of a frame could answer all the
+ * samples of an area light at once, by walking the tree with the whole bundle of shadow rays (the pyramid from the hit
+ * point to the light) and finding no triangle that any ray of the bundle could meet?
+ *
+ * Compiled together with the oracle's source (it needs the oracle's tree and its per-query work counters); built and
+ * driven by tools/sim_beam.py.
+ */
+#include "../oracle/srt_oracle.cpp"
+
+namespace {
+
+struct Beam {
+    V3 P;          /* apex: the hit point */
+    V3 S[4];       /* light corners */
+    V3 n[5];       /* inward unit normals: four sides through P, the light's plane */
+    float off[5];  /* plane offsets: inside means dot(n, x) - off >= 0 */
+    V3 lo, hi;     /* bounding box of apex and corners */
+    float r;       /* dilation: origin shift of the rays + slack */
+    float dmax;    /* longest direction */
+    bool ok;
+};
+
+Beam make_beam(V3 P, const float* L)
+{
+    Beam b;
+    b.P = P;
+    V3 p0 = v3(L + 1), e1 = v3(L + 4), e2 = v3(L + 7);
+    b.S[0] = p0, b.S[1] = p0 + e1, b.S[2] = (p0 + e1) + e2, b.S[3] = p0 + e2;
+    b.r = 0.001f + 1e-4f;
+    b.ok = true;
+    b.lo = b.hi = P;
+    b.dmax = 0;
+    V3 c = { 0, 0, 0 };
+    for (int k = 0; k < 4; ++k) {
+        b.lo = { fmin_std(b.lo.x, b.S[k].x), fmin_std(b.lo.y, b.S[k].y), fmin_std(b.lo.z, b.S[k].z) };
+        b.hi = { fmax_std(b.hi.x, b.S[k].x), fmax_std(b.hi.y, b.S[k].y), fmax_std(b.hi.z, b.S[k].z) };
+        b.dmax = fmax_std(b.dmax, length(b.S[k] - P));
+        c = c + b.S[k] * 0.25f;
+    }
+    for (int k = 0; k < 4; ++k) {
+        V3 a = b.S[k] - P, d = b.S[(k + 1) & 3] - P;
+        V3 n = cross(a, d);
+        float l = length(n);
+        if (!(l > 1e-12f)) {
+            b.ok = false;
+            return b;
+        }
+        n = n * (1.0f / l);
+        if (dot(n, c - P) < 0)
+            n = -n;
+        if (!(dot(n, c - P) > 1e-6f))
+            b.ok = false;
+        b.n[k] = n;
+        b.off[k] = dot(n, P);
+    }
+    V3 nl = normalize(cross(e1, e2));
+    if (dot(nl, P - b.S[0]) < 0)
+        nl = -nl;
+    if (!(dot(nl, P - b.S[0]) > 1e-4f))
+        b.ok = false;
+    b.n[4] = nl;
+    b.off[4] = dot(nl, b.S[0]);
+    return b;
+}
+
+/* may the bundle meet the box?  (conservative: false only when surely not) */
+bool beam_box(const Beam& b, const Box& x, float grow)
+{
+    const float r = b.r + grow;
+    if (x.lo.x - r > b.hi.x || x.hi.x + r < b.lo.x || x.lo.y - r > b.hi.y || x.hi.y + r < b.lo.y || x.lo.z - r > b.hi.z || x.hi.z + r < b.lo.z)
+        return false;
+    for (int k = 0; k < 5; ++k) {
+        const V3 n = b.n[k];
+        const V3 pv = { n.x >= 0 ? x.hi.x : x.lo.x, n.y >= 0 ? x.hi.y : x.lo.y, n.z >= 0 ? x.hi.z : x.lo.z };
+        if (dot(n, pv) - b.off[k] < -r)
+            return false;
+    }
+    return true;
+}
+
+/* may any ray of the bundle be accepted by the triangle with t < 0.99?  (conservative) */
+bool beam_triangle(const Beam& b, V3 v0, V3 v1, V3 v2, int* why)
+{
+    const float r = b.r;
+    *why = 0;
+    V3 lo = { fmin_std(v0.x, fmin_std(v1.x, v2.x)), fmin_std(v0.y, fmin_std(v1.y, v2.y)), fmin_std(v0.z, fmin_std(v1.z, v2.z)) };
+    V3 hi = { fmax_std(v0.x, fmax_std(v1.x, v2.x)), fmax_std(v0.y, fmax_std(v1.y, v2.y)), fmax_std(v0.z, fmax_std(v1.z, v2.z)) };
+    if (lo.x - r > b.hi.x || hi.x + r < b.lo.x || lo.y - r > b.hi.y || hi.y + r < b.lo.y || lo.z - r > b.hi.z || hi.z + r < b.lo.z)
+        return false;
+    for (int k = 0; k < 5; ++k) {
+        const V3 n = b.n[k];
+        if (dot(n, v0) - b.off[k] < -r && dot(n, v1) - b.off[k] < -r && dot(n, v2) - b.off[k] < -r)
+            return false;
+    }
+    /* the triangle's own plane */
+    V3 c = cross(v1 - v0, v2 - v0);
+    if (length(c) == 0.0f)
+        return false; /* the reference's test refuses a triangle without a normal */
+    V3 n = normalize(c);
+    const float D = dot(v0, n);
+    const float gP = dot(b.P, n) - D;
+    float mmin = FLT_MAX, mmax = -FLT_MAX;
+    for (int k = 0; k < 4; ++k) {
+        const float m = dot(n, b.S[k] - b.P);
+        mmin = fmin_std(mmin, m), mmax = fmax_std(mmax, m);
+    }
+    const float eps = 1e-5f;
+    if (mmin > 0) {
+        if (gP + 0.001f * mmin / b.dmax > eps)
+            return false;
+    } else if (mmax < 0) {
+        if (gP + 0.001f * mmax / b.dmax < -eps)
+            return false;
+    }
+    if (gP - 0.001f > eps && gP + mmin - 0.001f > eps)
+        return false;
+    if (gP + 0.001f < -eps && gP + mmax + 0.001f < -eps)
+        return false;
+    *why = 1;
+    return true;
+}
+
+
+/* A shadow walk over the four-wide coarse slots that is free to choose its order (exact whenever the ray cannot have a
+ * hit in [0.99, 1]).  mode 0: the reference's pop order; 1: nearest entry first; 2: farthest first; 3: the slot whose span
+ * along the ray lies nearest to t_guide first; 4: longest span first.  Returns occluded; work in *visits, *tris. */
+bool walk_order(Ctx& c, const Ray& ray, const HitInfo& like, int mode, float t_guide, double* visits, double* tris, float* t_found, int start = -1)
+{
+    const orc_bvh& bvh = c.bvh;
+    const float o[3] = { ray.o.x, ray.o.y, ray.o.z }, d[3] = { ray.d.x, ray.d.y, ray.d.z };
+    const Box& root = bvh.nodes.back().box;
+    const float rlo[3] = { root.lo.x, root.lo.y, root.lo.z };
+    CoarseRay cr;
+    for (int k = 0; k < 3; ++k) {
+        const float og = (o[k] - rlo[k]) * bvh.q_scale[k] + 1.0f;
+        cr.qi[k] = 1.0f / (d[k] * bvh.q_scale[k]);
+        cr.qc[k] = -(og * cr.qi[k]);
+    }
+    std::vector<int> stack;
+    int cur = start >= 0 ? start : (int)bvh.nodes.size() - 1;
+    for (;;) {
+        bool descended = false;
+        if (cur < 0 || bvh.nodes[cur].leaf) {
+            const int first = cur < 0 ? -(cur + 1) : bvh.nodes[cur].a, count = cur < 0 ? 1 : bvh.nodes[cur].b;
+            Ray r = ray;
+            HitInfo h = like;
+            bool hit = false;
+            for (int k = 0; k < count; ++k) {
+                TriRef t = bvh.order[first + k];
+                *tris += 1;
+                if (leaf_triangle(c, r, h, t.mesh, t.tri))
+                    hit = true;
+            }
+            if (hit && r.t < 0.99f) {
+                *t_found = r.t;
+                return true;
+            }
+        } else {
+            const Node& n = bvh.nodes[cur];
+            *visits += 1;
+            int slot[4], ns = 0;
+            for (int child : { n.b, n.a }) {
+                const Node& cn = bvh.nodes[child];
+                if (cn.leaf)
+                    slot[ns++] = child;
+                else
+                    slot[ns++] = cn.b, slot[ns++] = cn.a;
+            }
+            int singles = 0;
+            bool anyLeaf = false;
+            for (int k = 0; k < ns; ++k) {
+                const Node& sn = bvh.nodes[slot[k]];
+                anyLeaf = anyLeaf || sn.leaf;
+                singles += sn.leaf ? sn.b : 1;
+            }
+            if (anyLeaf && singles <= 4) {
+                int wide[4], nw = 0;
+                for (int k = 0; k < ns; ++k) {
+                    const Node& sn = bvh.nodes[slot[k]];
+                    if (sn.leaf && sn.b != 1)
+                        for (int j = 0; j < sn.b; ++j)
+                            wide[nw++] = -(sn.a + j + 1);
+                    else
+                        wide[nw++] = slot[k];
+                }
+                ns = nw;
+                for (int k = 0; k < ns; ++k)
+                    slot[k] = wide[k];
+            }
+            int met[4], nm = 0;
+            float key[4];
+            for (int k = 0; k < ns; ++k) {
+                const std::array<uint32_t, 3>& q = slot[k] < 0 ? bvh.tq[-(slot[k] + 1)] : bvh.cq[slot[k]];
+                float tl[3], th[3];
+                for (int a = 0; a < 3; ++a) {
+                    const float x = std::fmaf((float)(q[a] & 0xFFFFu), cr.qi[a], cr.qc[a]), y = std::fmaf((float)(q[a] >> 16), cr.qi[a], cr.qc[a]);
+                    tl[a] = fmin_std(x, y), th[a] = fmax_std(x, y);
+                }
+                const float tin = fmax_std(tl[0], fmax_std(tl[1], tl[2]));
+                const float tout = fmin_std(th[0], fmin_std(th[1], th[2]));
+                if (tin > tout || tout < 0.0f || tin > 1.0f)
+                    continue;
+                const float a = fmax_std(tin, 0.0f), b = fmin_std(tout, 1.0f);
+                float ky = (float)nm; /* mode 0: keep the slot order */
+                if (mode == 1)
+                    ky = a;
+                else if (mode == 2)
+                    ky = -b;
+                else if (mode == 3)
+                    ky = t_guide < a ? a - t_guide : (t_guide > b ? t_guide - b : 0.0f);
+                else if (mode == 4)
+                    ky = -(b - a);
+                else if (mode == 5)
+                    ky = std::fabs(0.5f * (a + b) - t_guide);
+                met[nm] = slot[k], key[nm] = ky, nm += 1;
+            }
+            /* stable insertion sort by key */
+            for (int i = 1; i < nm; ++i)
+                for (int j = i; j > 0 && key[j] < key[j - 1]; --j) {
+                    std::swap(key[j], key[j - 1]);
+                    std::swap(met[j], met[j - 1]);
+                }
+            for (int k = nm - 1; k > 0; --k)
+                stack.push_back(met[k]);
+            if (nm > 0) {
+                cur = met[0];
+                descended = true;
+            }
+        }
+        if (descended)
+            continue;
+        if (stack.empty())
+            return false;
+        cur = stack.back();
+        stack.pop_back();
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+/* out[0..]: see sim_beam.py */
+void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int light_index, int step, double* out)
+{
+    const orc_scene& s = bvh->s;
+    const float* L = s.lights + (size_t)ORC_LIGHT_STRIDE * light_index;
+    const Box& root = bvh->nodes.back().box;
+    const float grid = fmax_std(fmax_std(root.hi.x - root.lo.x, root.hi.y - root.lo.y), root.hi.z - root.lo.z) / 65533.0f;
+    std::vector<int> parent(bvh->nodes.size(), -1), leaf_of(bvh->order.size(), -1);
+    for (size_t i = 0; i < bvh->nodes.size(); ++i) {
+        const Node& n = bvh->nodes[i];
+        if (n.leaf)
+            for (int k = 0; k < n.b; ++k)
+                leaf_of[n.a + k] = (int)i;
+        else
+            parent[n.a] = parent[n.b] = (int)i;
+    }
+    double hits = 0, clean = 0, allvis = 0, allocc = 0, mixed = 0;
+    double cost_total = 0, cost_clean = 0, cost_allvis = 0, cost_allocc = 0, cost_mixed = 0;
+    double beam_visits = 0, beam_tris = 0, beam_visits_clean = 0, beam_tris_clean = 0, wrong = 0;
+    double fail_own = 0, fail_far = 0, fail_overflow = 0;
+    double order_work[6] = { 0, 0, 0, 0, 0, 0 }, order_occ[6] = { 0, 0, 0, 0, 0, 0 };
+    double top_tests[5] = {0,0,0,0,0}, top_roots[5] = {0,0,0,0,0}, top_visits[5] = {0,0,0,0,0}, top_tris[5] = {0,0,0,0,0}, top_occ[5] = {0,0,0,0,0};
+    double scout_work[4] = { 0, 0, 0, 0 }, scout_tried[4] = { 0, 0, 0, 0 }, scout_found[4] = { 0, 0, 0, 0 };
+    double vis_in_unclean = 0, q_total = 0, zero_q = 0, zero_cost = 0, zero_vis = 0, vis_cost = 0, occ_cost = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : hits, clean, allvis, allocc, mixed, cost_total, cost_clean, cost_allvis, cost_allocc, cost_mixed, beam_visits, beam_tris, beam_visits_clean, beam_tris_clean, wrong, fail_own, fail_far, fail_overflow, vis_in_unclean, q_total, zero_q, zero_cost, zero_vis, vis_cost, occ_cost, scout_work[:4], scout_tried[:4], scout_found[:4], order_work[:6], order_occ[:6], top_tests[:5], top_roots[:5], top_visits[:5], top_tris[:5], top_occ[:5])
+    for (int y = 0; y < cam->height; y += step) {
+        for (int x = 0; x < cam->width; x += step) {
+            Ctx c { *bvh, features, 5, 0u };
+            float nx = (float)x / (float)cam->width * 2.0f - 1.0f, ny = (float)y / (float)cam->height * 2.0f - 1.0f;
+            Ray ray = camera_ray(*cam, nx, ny);
+            HitInfo hit;
+            if (!intersect(c, ray, hit))
+                continue;
+            hits += 1;
+            V3 P = ray.o + ray.d * ray.t;
+            /* the 100 queries, with their work */
+            V3 p0 = v3(L + 1), e01 = v3(L + 4), e02 = v3(L + 7);
+            int nvis = 0;
+            orc_counters before = c.cnt;
+            for (int i = 0; i < 10; ++i)
+                for (int j = 0; j < 10; ++j) {
+                    float r1 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 0);
+                    float r2 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 1);
+                    float u = ((float)i + r1) / 10.0f, v = ((float)j + r2) / 10.0f;
+                    V3 pos = (p0 + (u * e01)) + (v * e02);
+                    orc_counters b4 = c.cnt;
+                    const bool vis = visibility(c, pos, ray, hit) != 0.0f;
+                    nvis += vis;
+                    V3 col = { 1, 1, 1 };
+                    V3 term = compute_shading(pos, col, ray, hit.normal, hit.material.kd, hit.material.ks, hit.material.shininess);
+                    const double qc = (double)(c.cnt.inner_visits - b4.inner_visits) + (double)(c.cnt.tri_tests - b4.tri_tests);
+                    if (term.x == 0 && term.y == 0 && term.z == 0)
+                        zero_q += 1, zero_cost += qc, zero_vis += vis;
+                    if (vis) vis_cost += qc; else occ_cost += qc;
+                }
+            const double cost = (double)(c.cnt.inner_visits - before.inner_visits) + (double)(c.cnt.tri_tests - before.tri_tests);
+            cost_total += cost;
+            q_total += 100;
+            if (nvis == 100)
+                allvis += 1, cost_allvis += cost;
+            else if (nvis == 0)
+                allocc += 1, cost_allocc += cost;
+            else
+                mixed += 1, cost_mixed += cost;
+            /* free traversal orders */
+            {
+                float tg = 0.5f;
+                bool have = false;
+                for (int i = 0; i < 10; ++i)
+                    for (int j = 0; j < 10; ++j) {
+                        float r1 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 0);
+                        float r2 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 1);
+                        float u = ((float)i + r1) / 10.0f, v = ((float)j + r2) / 10.0f;
+                        V3 pos = (p0 + (u * e01)) + (v * e02);
+                        Ray nr = { P, pos - P, 1.0f };
+                        nr.o = nr.o + normalize(nr.d) * 0.001f;
+                        for (int m = 0; m < 6; ++m) {
+                            double vv = 0, tt = 0;
+                            float tf = -1;
+                            /* the guide: t of the previous occluded sample of this hit (sequential stand-in for a scout) */
+                            bool occ = walk_order(c, nr, hit, m, have ? tg : 0.5f, &vv, &tt, &tf);
+                            order_work[m] += vv + tt;
+                            order_occ[m] += occ;
+                            if (m == 5 && occ)
+                                tg = tf, have = true;
+                        }
+                    }
+            }
+            /* top levels walked once per hit by the bundle: the samples start from the listed sub-trees */
+            {
+                Beam b = make_beam(P, L);
+                for (int D = 2; D <= 4; ++D) { /* wide levels folded into the list */
+                    std::vector<int> roots, frontier;
+                    frontier.push_back((int)bvh->nodes.size() - 1);
+                    double tests = 0;
+                    bool usable = b.ok;
+                    for (int lev = 0; lev < D && usable; ++lev) {
+                        std::vector<int> next;
+                        for (int cur : frontier) {
+                            const Node& n = bvh->nodes[cur];
+                            if (n.leaf) { usable = false; break; }
+                            for (int child : { n.b, n.a }) {
+                                const Node& cn = bvh->nodes[child];
+                                if (cn.leaf) { usable = false; break; }
+                                for (int g : { cn.b, cn.a }) {
+                                    tests += 1;
+                                    if (beam_box(b, bvh->nodes[g].box, 3.0f * grid))
+                                        next.push_back(g);
+                                }
+                            }
+                        }
+                        frontier.swap(next);
+                    }
+                    if (!usable) continue;
+                    top_tests[D] += tests;
+                    top_roots[D] += (double)frontier.size();
+                    for (int i = 0; i < 10; ++i)
+                        for (int j = 0; j < 10; ++j) {
+                            float r1 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 0);
+                            float r2 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 1);
+                            float u = ((float)i + r1) / 10.0f, v = ((float)j + r2) / 10.0f;
+                            V3 pos = (p0 + (u * e01)) + (v * e02);
+                            Ray nr = { P, pos - P, 1.0f };
+                            nr.o = nr.o + normalize(nr.d) * 0.001f;
+                            double vv = 0, tt = 0;
+                            float tf;
+                            bool occ = false;
+                            for (int root : frontier) {
+                                if (bvh->nodes[root].leaf) { usable = false; break; }
+                                if (walk_order(c, nr, hit, 0, 0.5f, &vv, &tt, &tf, root)) { occ = true; break; }
+                            }
+                            top_visits[D] += vv, top_tris[D] += tt, top_occ[D] += occ;
+                        }
+                }
+            }
+            /* the bundle */
+            Beam b = make_beam(P, L);
+            bool ok = b.ok;
+            double bv = 0, bt = 0;
+            int failed_near = 0;
+            if (ok) {
+                std::vector<int> stack;
+                stack.push_back((int)bvh->nodes.size() - 1);
+                while (!stack.empty() && ok) {
+                    const int cur = stack.back();
+                    stack.pop_back();
+                    const Node& n = bvh->nodes[cur];
+                    if (n.leaf) {
+                        for (int k = 0; k < n.b && ok; ++k) {
+                            TriRef t = bvh->order[n.a + k];
+                            const uint32_t* tr = tri(s, t.mesh, t.tri);
+                            V3 v0 = v3(vert(s, t.mesh, tr[0])), v1 = v3(vert(s, t.mesh, tr[1])), v2 = v3(vert(s, t.mesh, tr[2]));
+                            bt += 1;
+                            int why;
+                            if (beam_triangle(b, v0, v1, v2, &why)) {
+                                ok = false;
+                                V3 cc = ((v0 + v1) + v2) / 3.0f;
+                                failed_near = length(cc - P) < 0.05f;
+                            }
+                        }
+                        continue;
+                    }
+                    bv += 1; /* one wide visit: up to four grandchildren */
+                    int slot[4], ns = 0;
+                    for (int child : { n.b, n.a }) {
+                        const Node& cn = bvh->nodes[child];
+                        if (cn.leaf)
+                            slot[ns++] = child;
+                        else
+                            slot[ns++] = cn.b, slot[ns++] = cn.a;
+                    }
+                    for (int k = 0; k < ns; ++k)
+                        if (beam_box(b, bvh->nodes[slot[k]].box, 3.0f * grid))
+                            stack.push_back(slot[k]);
+                    if (stack.size() > 24) {
+                        ok = false;
+                        fail_overflow += 1;
+                    }
+                }
+            }
+            beam_visits += bv, beam_tris += bt;
+            if (ok) {
+                clean += 1;
+                cost_clean += cost;
+                beam_visits_clean += bv, beam_tris_clean += bt;
+                if (nvis != 100)
+                    wrong += 1;
+            } else {
+                vis_in_unclean += nvis;
+                if (failed_near)
+                    fail_own += 1;
+                else
+                    fail_far += 1;
+            }
+        }
+    }
+    double* o = out;
+    *o++ = hits, *o++ = clean, *o++ = allvis, *o++ = allocc, *o++ = mixed;
+    *o++ = cost_total, *o++ = cost_clean, *o++ = cost_allvis, *o++ = cost_allocc, *o++ = cost_mixed;
+    *o++ = beam_visits, *o++ = beam_tris, *o++ = beam_visits_clean, *o++ = beam_tris_clean, *o++ = wrong;
+    *o++ = fail_own, *o++ = fail_far, *o++ = fail_overflow, *o++ = vis_in_unclean, *o++ = q_total; for (int K = 0; K < 4; ++K) *o++ = scout_work[K], *o++ = scout_tried[K], *o++ = scout_found[K];
+    for (int m = 0; m < 6; ++m) *o++ = order_work[m], *o++ = order_occ[m];
+    for (int D = 2; D <= 4; ++D) *o++ = top_tests[D], *o++ = top_roots[D], *o++ = top_visits[D], *o++ = top_tris[D], *o++ = top_occ[D];
+    *o++ = zero_q, *o++ = zero_cost, *o++ = zero_vis, *o++ = vis_cost, *o++ = occ_cost;
+}
+}
