@@ -186,6 +186,32 @@ SRT_DI bool tri_test(const float4* __restrict__ rec, f3 o, f3 d, float& T)
     return true;
 }
 
+/* tri_test without branches, for the shadow walk: all six quarters of the record are requested at once and every
+ * lane runs the whole test; the early exits of tri_test become terms of the final conjunction.  Same operations on the
+ * same operands in the same order, so the same decision and the same distance bit for bit (a lane that tri_test would
+ * have sent away early computes values nobody looks at: a division by zero raises nothing here).  One round trip to
+ * memory per triangle instead of two (plane first, the rest after the plane test), which is what a leaf step of the
+ * shadow walk waits for. */
+SRT_DI bool tri_test_flat(const float4* __restrict__ rec, f3 o, f3 d, float& T)
+{
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+    const f3 n = xyz(q0);
+    const float D = q0.w;
+    const float dn = dot3(d, n);
+    const float on = dot3(o, n);
+    const float nt = (D - on) / dn;
+    const bool plane = !(dn == 0.0f || on == D) && !(nt < 0) && (nt <= T);
+    const f3 p = o + d * nt;
+    const f3 v0 = xyz(q1), v1 = xyz(q2), v2 = mk3(q3.x, q3.y, q3.z);
+    const f3 c0 = mk3(q3.w, q4.x, q4.y), c1 = mk3(q4.z, q4.w, q5.x), c2 = mk3(q5.y, q5.z, q5.w);
+    const bool s0 = dot3(cross3(v2 - v1, p - v1), c0) >= 0;
+    const bool s1 = dot3(cross3(v2 - v0, p - v0), c1) >= 0;
+    const bool s2 = dot3(cross3(v1 - v0, p - v0), c2) >= 0;
+    const bool hit = plane && s0 && s1 && s2;
+    T = hit ? nt : T;
+    return hit;
+}
+
 /* The two halves of tri_test, for callers that test several triangles of a leaf side by side.
  * tri_plane: intersectRayWithPlane up to, not including, the comparison with the ray's t (reference
  * src/intersect.cpp:28-43): false when the ray is parallel to the plane, starts on it or meets it behind its origin. */

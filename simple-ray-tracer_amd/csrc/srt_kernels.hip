@@ -945,7 +945,7 @@ SRT_DI void hit_ray(const RenderDev& rp, int depth, const HitQ& hq, const float4
 #endif
 #define SRT_LDS_LIGHTS 16u
 #ifndef SRT_WIDE_LDS_NODES
-#define SRT_WIDE_LDS_NODES 21u /* wide records (64 bytes each) of the tree's top levels a block of the shadow kernel keeps in LDS */
+#define SRT_WIDE_LDS_NODES 85u /* wide records (64 bytes each) of the tree's top levels a block of the shadow kernel keeps in LDS: four whole levels */
 #endif
 #ifndef SRT_SVOTE_INNER_W
 /* Vote weights of the shadow walk, box step : leaf step (dragon / teapot shadow launch: 1:2 141.4 / 0.752 ms, 3:4 138.7 /
@@ -1304,7 +1304,7 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
-        if (tri_test(tri_record(sc, first + k), w.o, w.d, T))
+        if (tri_test_flat(tri_record(sc, first + k), w.o, w.d, T))
             hit = true;
     }
     if (hit) {
@@ -1326,7 +1326,10 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
  * consecutive items, consecutive items going to consecutive idle lanes, so its lanes keep working on neighbouring
  * samples of the same few hits (same origin, nearby targets on the light). */
 #ifndef SRT_SHADOW_WAVES
-#define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 7) /* waves per SIMD the register allocation aims at */
+/* waves per SIMD the register allocation aims at.  Six: 85 registers, nothing spilled, and room in LDS for four levels of
+ * top records; with the walk's instruction stream as short as it is now, 5, 6 and 7 waves measure within 0.5 % of each
+ * other (7 waves spill nine registers in the refill path). */
+#define SRT_SHADOW_WAVES (SRT_SHADOW_BLOCK >= 1024 ? 4 : 6)
 #endif
 template <bool CULL, bool COUNT, bool COARSE>
 __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_shadow(SceneDev sc, RenderDev rp, int depth, HitQ hq, const uint32_t* hq_count,

@@ -261,11 +261,12 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
     double cost_total = 0, cost_clean = 0, cost_allvis = 0, cost_allocc = 0, cost_mixed = 0;
     double beam_visits = 0, beam_tris = 0, beam_visits_clean = 0, beam_tris_clean = 0, wrong = 0;
     double fail_own = 0, fail_far = 0, fail_overflow = 0;
+    double fallbacks = 0;
     double order_work[6] = { 0, 0, 0, 0, 0, 0 }, order_occ[6] = { 0, 0, 0, 0, 0, 0 };
     double top_tests[5] = {0,0,0,0,0}, top_roots[5] = {0,0,0,0,0}, top_visits[5] = {0,0,0,0,0}, top_tris[5] = {0,0,0,0,0}, top_occ[5] = {0,0,0,0,0};
     double scout_work[4] = { 0, 0, 0, 0 }, scout_tried[4] = { 0, 0, 0, 0 }, scout_found[4] = { 0, 0, 0, 0 };
     double vis_in_unclean = 0, q_total = 0, zero_q = 0, zero_cost = 0, zero_vis = 0, vis_cost = 0, occ_cost = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : hits, clean, allvis, allocc, mixed, cost_total, cost_clean, cost_allvis, cost_allocc, cost_mixed, beam_visits, beam_tris, beam_visits_clean, beam_tris_clean, wrong, fail_own, fail_far, fail_overflow, vis_in_unclean, q_total, zero_q, zero_cost, zero_vis, vis_cost, occ_cost, scout_work[:4], scout_tried[:4], scout_found[:4], order_work[:6], order_occ[:6], top_tests[:5], top_roots[:5], top_visits[:5], top_tris[:5], top_occ[:5])
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : hits, clean, allvis, allocc, mixed, cost_total, cost_clean, cost_allvis, cost_allocc, cost_mixed, beam_visits, beam_tris, beam_visits_clean, beam_tris_clean, wrong, fail_own, fail_far, fail_overflow, vis_in_unclean, q_total, zero_q, zero_cost, zero_vis, vis_cost, occ_cost, scout_work[:4], scout_tried[:4], scout_found[:4], order_work[:6], order_occ[:6], top_tests[:5], top_roots[:5], top_visits[:5], top_tris[:5], top_occ[:5], fallbacks)
     for (int y = 0; y < cam->height; y += step) {
         for (int x = 0; x < cam->width; x += step) {
             Ctx c { *bvh, features, 5, 0u };
@@ -286,6 +287,14 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
                     float r2 = rand01(0, (uint32_t)(y * cam->width + x), 0, (uint32_t)light_index, (uint32_t)(i * 10 + j), 1);
                     float u = ((float)i + r1) / 10.0f, v = ((float)j + r2) / 10.0f;
                     V3 pos = (p0 + (u * e01)) + (v * e02);
+                    {
+                        Ray nr = { P, pos - P, 1.0f };
+                        nr.o = nr.o + normalize(nr.d) * 0.001f;
+                        bool occ2 = false;
+                        Ctx c2 { *bvh, features, 5, 0u };
+                        if (!shadow_coarse(c2, nr, hit, occ2))
+                            fallbacks += 1;
+                    }
                     orc_counters b4 = c.cnt;
                     const bool vis = visibility(c, pos, ray, hit) != 0.0f;
                     nvis += vis;
@@ -444,6 +453,7 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
     *o++ = fail_own, *o++ = fail_far, *o++ = fail_overflow, *o++ = vis_in_unclean, *o++ = q_total; for (int K = 0; K < 4; ++K) *o++ = scout_work[K], *o++ = scout_tried[K], *o++ = scout_found[K];
     for (int m = 0; m < 6; ++m) *o++ = order_work[m], *o++ = order_occ[m];
     for (int D = 2; D <= 4; ++D) *o++ = top_tests[D], *o++ = top_roots[D], *o++ = top_visits[D], *o++ = top_tris[D], *o++ = top_occ[D];
+    *o++ = fallbacks;
     *o++ = zero_q, *o++ = zero_cost, *o++ = zero_vis, *o++ = vis_cost, *o++ = occ_cost;
 }
 }

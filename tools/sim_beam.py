@@ -48,7 +48,7 @@ out = (C.c_double * 80)()
 L.sim_beam(bvh.h, C.byref(cam), feat, light, step, out)
 names = ["hits", "clean", "allvis", "allocc", "mixed", "cost_total", "cost_clean", "cost_allvis", "cost_allocc", "cost_mixed",
          "beam_visits", "beam_tris", "beam_visits_clean", "beam_tris_clean", "wrong", "fail_near", "fail_far", "fail_overflow",
-         "vis_in_unclean", "q_total", "scout_work0", "scout_tried0", "scout_found0", "scout_work1", "scout_tried1", "scout_found1", "scout_work2", "scout_tried2", "scout_found2", "scout_work3", "scout_tried3", "scout_found3", "order_work0", "order_occ0", "order_work1", "order_occ1", "order_work2", "order_occ2", "order_work3", "order_occ3", "order_work4", "order_occ4", "order_work5", "order_occ5", "top_tests2", "top_roots2", "top_visits2", "top_tris2", "top_occ2", "top_tests3", "top_roots3", "top_visits3", "top_tris3", "top_occ3", "top_tests4", "top_roots4", "top_visits4", "top_tris4", "top_occ4", "zero_q", "zero_cost", "zero_vis", "vis_cost", "occ_cost"]
+         "vis_in_unclean", "q_total", "scout_work0", "scout_tried0", "scout_found0", "scout_work1", "scout_tried1", "scout_found1", "scout_work2", "scout_tried2", "scout_found2", "scout_work3", "scout_tried3", "scout_found3", "order_work0", "order_occ0", "order_work1", "order_occ1", "order_work2", "order_occ2", "order_work3", "order_occ3", "order_work4", "order_occ4", "order_work5", "order_occ5", "top_tests2", "top_roots2", "top_visits2", "top_tris2", "top_occ2", "top_tests3", "top_roots3", "top_visits3", "top_tris3", "top_occ3", "top_tests4", "top_roots4", "top_visits4", "top_tris4", "top_occ4", "fallbacks", "zero_q", "zero_cost", "zero_vis", "vis_cost", "occ_cost"]
 r = dict(zip(names, out))
 for k in names:
     print(f"{k:20s} {r[k]:.0f}")
@@ -68,3 +68,4 @@ for k in (2, 3, 4):
     print(f"top {k} wide levels walked per hit by the bundle: {r[f'top_tests{k}']/h:.1f} box tests and {r[f'top_roots{k}']/h:.2f} listed sub-trees per hit; "
           f"per query {r[f'top_visits{k}']/r['q_total']:.2f} wide visits + {r[f'top_tris{k}']/r['q_total']:.2f} triangle tests "
           f"(work {(r[f'top_visits{k}']+r[f'top_tris{k}'])/r['order_work0']:.3f} of plain), occluded {r[f'top_occ{k}']:.0f}")
+print(f"queries handed to the exact walk (stack capacity SRT_WIDE_CAP={os.environ.get('SRT_WIDE_CAP', 'default')}): {r['fallbacks']:.0f} of {r['q_total']:.0f} = {r['fallbacks']/r['q_total']:.5f}")
