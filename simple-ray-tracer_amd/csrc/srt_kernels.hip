@@ -77,6 +77,7 @@ struct SceneDev {
     uint32_t wide_cap;         /* pending siblings a shadow query may stack on the wide nodes; beyond: the exact walk */
     uint32_t n_wide;           /* records in wnodes */
     uint32_t n_top;            /* the first n_top records are the top levels of the tree: the shadow kernel keeps them in LDS */
+    const float4* stris;       /* 48-byte triangle records of the coarse shadow walk (normal + vertices), same order as tris; null: not derived */
     uint32_t coarse_ok;        /* wnodes is usable: every child box lies inside the root box */
 };
 
@@ -166,6 +167,12 @@ SRT_DI const float4* tri_record(const SceneDev& sc, uint32_t i)
     uint32_t off = i * 96u;
     asm volatile("" : "+v"(off));
     return (const float4*)((const char*)sc.tris + off);
+}
+SRT_DI const float4* shadow_tri_record(const SceneDev& sc, uint32_t i)
+{
+    uint32_t off = i * 48u;
+    asm volatile("" : "+v"(off));
+    return (const float4*)((const char*)sc.stris + off);
 }
 /* Lane mask of a predicate, straight from the compare (HIP's __ballot takes an int: the predicate would be turned into
  * 0 / 1 and compared again, two vector instructions per vote). */
@@ -286,7 +293,7 @@ SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
     for (uint32_t k = 0; k < cnt; ++k) {
         if (COUNT)
             st.tri += 1;
-        if (tri_test(tri_record(sc, first + k), w.o, w.d, w.T)) {
+        if (tri_test_flat(tri_record(sc, first + k), w.o, w.d, w.T)) {
             w.C = min_std(w.C, w.T);
             w.hitTri = first + k;
         }
@@ -1210,6 +1217,33 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_widen(const float4* __restrict__ 
         atomicOr(bad_flag, 1u);
 }
 
+/* The shadow walk's 48-byte triangle records (tri_test_compact): unit normal and vertices of every traversal record, in
+ * the same order.  A record only qualifies if what the compact test recomputes is what the full record stores: D equal
+ * as a number, the three second operands of the inside tests bit for bit.  Records made by k_build_triangles or by the
+ * host mirror's flatten() always do; a table uploaded with other values raises the flag and the scene keeps the full
+ * records for its shadow walk. */
+__global__ __launch_bounds__(SRT_BLOCK) void k_compact_triangles(const float4* __restrict__ tris, uint32_t n, float4* __restrict__ out, uint32_t* bad_flag)
+{
+    const uint32_t i = blockIdx.x * SRT_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4* rec = tris + 6ull * i;
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+    const f3 nrm = xyz(q0), v0 = xyz(q1), v1 = xyz(q2), v2 = mk3(q3.x, q3.y, q3.z);
+    const f3 e21 = v2 - v1, e20 = v2 - v0, e10 = v1 - v0;
+    const f3 c0 = cross3(e21, v0 - v1), c1 = cross3(e20, e10), c2 = cross3(e10, e20);
+    const float stored[9] = { q3.w, q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w };
+    const float made[9] = { c0.x, c0.y, c0.z, c1.x, c1.y, c1.z, c2.x, c2.y, c2.z };
+    bool same = dot3(v0, nrm) == q0.w;
+    for (int k = 0; k < 9; ++k)
+        same = same && __float_as_uint(stored[k]) == __float_as_uint(made[k]);
+    out[3ull * i] = make_float4(nrm.x, nrm.y, nrm.z, v0.x);
+    out[3ull * i + 1] = make_float4(v0.y, v0.z, v1.x, v1.y);
+    out[3ull * i + 2] = make_float4(v1.z, v2.x, v2.y, v2.z);
+    if (!same)
+        atomicOr(bad_flag, 1u);
+}
+
 /* Grid-space constants of a query's ray; false when the origin is too far from the root box for the margin to hold. */
 SRT_DI bool coarse_ray(const SceneDev& sc, Walk& w)
 {
@@ -1290,7 +1324,7 @@ SRT_DI bool swalk_inner_wide(const SceneDev& sc, const uint4* top, Walk& w, uint
 }
 
 /* Leaf visit of the common shadow walk.  Returns 0: no hit, walk on; 1: occluded; 2: first hit in [0.99, 1]. */
-template <bool COUNT>
+template <bool COUNT, bool COMPACT>
 SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& st)
 {
     const uint32_t first = w.cur & 0x00FFFFFFu;
@@ -1301,11 +1335,20 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
      * test).  Most visits are of a single triangle: the wide records list the triangles of small leaves one by one.
      * (Testing a leaf's triangles in pairs and recomputing the stored operands from the vertices paid while the kernel
      * was short of loads per lane; with the wide records it is short of vector instructions: 107.9 -> 106.1 ms.) */
-    for (uint32_t k = 0; k < cnt; ++k) {
-        if (COUNT)
-            st.tri += 1;
-        if (tri_test_flat(tri_record(sc, first + k), w.o, w.d, T))
-            hit = true;
+    if (COMPACT) {
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (COUNT)
+                st.tri += 1;
+            if (tri_test_compact(shadow_tri_record(sc, first + k), w.o, w.d, T))
+                hit = true;
+        }
+    } else {
+        for (uint32_t k = 0; k < cnt; ++k) {
+            if (COUNT)
+                st.tri += 1;
+            if (tri_test_flat(tri_record(sc, first + k), w.o, w.d, T))
+                hit = true;
+        }
     }
     if (hit) {
         w.cur = SRT_WALK_DONE;
@@ -1539,8 +1582,9 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
         } else {
             if (COUNT && (int)lane == __ffsll((long long)mLeaf) - 1)
                 st.wave_leaf += 1;
+            /* (one branch on a scalar per leaf step; the coarse walk's scenes all but always have the compact records) */
             if (atLeaf)
-                verdict = swalk_leaf<COUNT>(sc, w, stk, st);
+                verdict = (COARSE && sc.stris) ? swalk_leaf<COUNT, true>(sc, w, stk, st) : swalk_leaf<COUNT, false>(sc, w, stk, st);
         }
         if (busy && w.cur == SRT_WALK_DONE) {
             if (verdict == 2)
@@ -2611,7 +2655,7 @@ static int fill_grids(srt_device* d, srt_scene* sc)
 static int scene_coarsen(srt_scene* s)
 {
     SceneDev& v = s->view;
-    v.wnodes = nullptr, v.coarse_ok = 0, v.wide_cap = 0, v.n_wide = 0, v.n_top = 0;
+    v.wnodes = nullptr, v.coarse_ok = 0, v.wide_cap = 0, v.n_wide = 0, v.n_top = 0, v.stris = nullptr;
     GridMap g;
     for (int k = 0; k < 3; ++k) {
         const float ext = v.root_hi[k] - v.root_lo[k];
@@ -2685,6 +2729,28 @@ static int scene_coarsen(srt_scene* s)
     v.n_wide = n_wide;
     v.n_top = n_top;
     v.coarse_ok = bad ? 0u : 1u;
+    /* the coarse walk's compact triangle records */
+    if (v.coarse_ok && v.n_tris) {
+        void *ct = nullptr, *cflag = nullptr;
+        uint32_t differs = 1;
+        HIPCHK(hipMalloc(&ct, (size_t)v.n_tris * 48));
+        s->allocs.push_back(ct);
+        e = hipMalloc(&cflag, 4);
+        if (e == hipSuccess)
+            e = hipMemset(cflag, 0, 4);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_compact_triangles, dim3((v.n_tris + SRT_BLOCK - 1) / SRT_BLOCK), dim3(SRT_BLOCK), 0, 0, v.tris, v.n_tris, (float4*)ct, (uint32_t*)cflag);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpy(&differs, cflag, 4, hipMemcpyDeviceToHost);
+        if (cflag)
+            (void)hipFree(cflag);
+        if (e != hipSuccess)
+            return fail(SRT_ERR_HIP, "compact triangle records: %s", hipGetErrorString(e));
+        if (!differs && !getenv("SRT_FULL_SHADOW_TRIANGLES"))
+            v.stris = (const float4*)ct;
+    }
     return SRT_OK;
 }
 

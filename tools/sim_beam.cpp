@@ -237,6 +237,141 @@ bool walk_order(Ctx& c, const Ray& ray, const HitInfo& like, int mode, float t_g
     }
 }
 
+
+/* ---- a surface-area-heuristic tree over the same triangles, for shadow queries only (any accepted hit below 0.99
+ * answers; order and shape of the tree do not matter to the answer when no hit in [0.99, 1] is possible) */
+struct SNode {
+    Box box;
+    int left, right; /* inner: children; leaf: left = -1, right = triangle position in order[] ... */
+    int first, count;
+};
+struct SahTree {
+    std::vector<SNode> nodes;
+    std::vector<int> tri; /* positions in bvh.order */
+};
+static inline float half_area(const Box& b)
+{
+    const float dx = b.hi.x - b.lo.x, dy = b.hi.y - b.lo.y, dz = b.hi.z - b.lo.z;
+    return dx * dy + dy * dz + dz * dx;
+}
+static inline void grow(Box& b, const Box& o)
+{
+    b.lo = { fmin_std(b.lo.x, o.lo.x), fmin_std(b.lo.y, o.lo.y), fmin_std(b.lo.z, o.lo.z) };
+    b.hi = { fmax_std(b.hi.x, o.hi.x), fmax_std(b.hi.y, o.hi.y), fmax_std(b.hi.z, o.hi.z) };
+}
+static int sah_build(SahTree& t, const std::vector<Box>& tb, const std::vector<V3>& tc, int first, int count, int leaf_max)
+{
+    SNode n;
+    n.box = { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
+    Box cb = n.box;
+    for (int i = first; i < first + count; ++i) {
+        grow(n.box, tb[t.tri[i]]);
+        const V3 c = tc[t.tri[i]];
+        grow(cb, Box { c, c });
+    }
+    n.left = n.right = -1, n.first = first, n.count = count;
+    const int me = (int)t.nodes.size();
+    t.nodes.push_back(n);
+    if (count <= leaf_max)
+        return me;
+    const int NB = 16;
+    float best = FLT_MAX;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = axis_of(cb.lo, a), hi = axis_of(cb.hi, a);
+        if (!(hi > lo))
+            continue;
+        Box bb[NB];
+        int bc[NB];
+        for (int k = 0; k < NB; ++k)
+            bb[k] = { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } }, bc[k] = 0;
+        const float sc = NB / (hi - lo);
+        for (int i = first; i < first + count; ++i) {
+            int k = (int)((axis_of(tc[t.tri[i]], a) - lo) * sc);
+            k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+            grow(bb[k], tb[t.tri[i]]);
+            bc[k] += 1;
+        }
+        float ra[NB];
+        int rc[NB];
+        Box acc = { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
+        int cnt = 0;
+        for (int k = NB - 1; k > 0; --k) {
+            if (bc[k]) grow(acc, bb[k]);
+            cnt += bc[k];
+            ra[k] = cnt ? half_area(acc) : 0.0f, rc[k] = cnt;
+        }
+        acc = { { FLT_MAX, FLT_MAX, FLT_MAX }, { -FLT_MAX, -FLT_MAX, -FLT_MAX } };
+        cnt = 0;
+        for (int k = 0; k < NB - 1; ++k) {
+            if (bc[k]) grow(acc, bb[k]);
+            cnt += bc[k];
+            if (cnt == 0 || rc[k + 1] == 0)
+                continue;
+            const float cost = half_area(acc) * cnt + ra[k + 1] * rc[k + 1];
+            if (cost < best)
+                best = cost, best_axis = a, best_bin = k;
+        }
+    }
+    int mid;
+    if (best_axis < 0) {
+        mid = first + count / 2;
+    } else {
+        const float lo = axis_of(cb.lo, best_axis), hi = axis_of(cb.hi, best_axis);
+        const float sc = NB / (hi - lo);
+        auto it = std::partition(t.tri.begin() + first, t.tri.begin() + first + count, [&](int ti) {
+            int k = (int)((axis_of(tc[ti], best_axis) - lo) * sc);
+            k = k < 0 ? 0 : (k >= NB ? NB - 1 : k);
+            return k <= best_bin;
+        });
+        mid = (int)(it - t.tri.begin());
+        if (mid == first || mid == first + count)
+            mid = first + count / 2;
+    }
+    const int l = sah_build(t, tb, tc, first, mid - first, leaf_max);
+    const int r = sah_build(t, tb, tc, mid, first + count - mid, leaf_max);
+    t.nodes[me].left = l, t.nodes[me].right = r;
+    return me;
+}
+/* any-hit walk of the binary SAH tree on exact boxes; mode 0: left child first, 1: nearer child first, 2: farther first */
+static bool sah_walk(Ctx& c, const SahTree& t, const Ray& ray, const HitInfo& like, int mode, double* visits, double* tris, int* maxsp)
+{
+    const orc_bvh& bvh = c.bvh;
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    float val;
+    { Ray r0 = ray; if (!slab(t.nodes[0].box, r0, val)) return false; }
+    while (sp > 0) {
+        const SNode& n = t.nodes[stack[--sp]];
+        if (n.left < 0) {
+            Ray r = ray;
+            HitInfo h = like;
+            bool hit = false;
+            for (int k = 0; k < n.count; ++k) {
+                TriRef tr = bvh.order[t.tri[n.first + k]];
+                *tris += 1;
+                if (leaf_triangle(c, r, h, tr.mesh, tr.tri))
+                    hit = true;
+            }
+            if (hit && r.t < 0.99f)
+                return true;
+            continue;
+        }
+        *visits += 1;
+        float vl, vr;
+        Ray r1 = ray;
+        const bool pl = slab(t.nodes[n.left].box, r1, vl), pr = slab(t.nodes[n.right].box, r1, vr);
+        int a = n.left, b = n.right;
+        bool pa = pl, pb = pr;
+        if ((mode == 1 && vr < vl) || (mode == 2 && vr > vl))
+            std::swap(a, b), std::swap(pa, pb);
+        if (pb) stack[sp++] = b;
+        if (pa) stack[sp++] = a;
+        if (sp > *maxsp) *maxsp = sp;
+    }
+    return false;
+}
+
 } // namespace
 
 extern "C" {
@@ -262,11 +397,28 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
     double beam_visits = 0, beam_tris = 0, beam_visits_clean = 0, beam_tris_clean = 0, wrong = 0;
     double fail_own = 0, fail_far = 0, fail_overflow = 0;
     double fallbacks = 0;
+    SahTree sah[2];
+    {
+        std::vector<Box> tb(bvh->order.size());
+        std::vector<V3> tc(bvh->order.size());
+        for (size_t i = 0; i < bvh->order.size(); ++i) {
+            tb[i] = get_box(s, &bvh->order[i], &bvh->order[i] + 1);
+            tc[i] = (tb[i].lo + tb[i].hi) * 0.5f;
+        }
+        for (int v = 0; v < 2; ++v) {
+            sah[v].tri.resize(bvh->order.size());
+            for (size_t i = 0; i < bvh->order.size(); ++i)
+                sah[v].tri[i] = (int)i;
+            sah_build(sah[v], tb, tc, 0, (int)bvh->order.size(), v == 0 ? 1 : 2);
+        }
+    }
+    double sah_visits[6] = {0,0,0,0,0,0}, sah_tris[6] = {0,0,0,0,0,0}, sah_occ[6] = {0,0,0,0,0,0};
+    int sah_maxsp = 0;
     double order_work[6] = { 0, 0, 0, 0, 0, 0 }, order_occ[6] = { 0, 0, 0, 0, 0, 0 };
     double top_tests[5] = {0,0,0,0,0}, top_roots[5] = {0,0,0,0,0}, top_visits[5] = {0,0,0,0,0}, top_tris[5] = {0,0,0,0,0}, top_occ[5] = {0,0,0,0,0};
     double scout_work[4] = { 0, 0, 0, 0 }, scout_tried[4] = { 0, 0, 0, 0 }, scout_found[4] = { 0, 0, 0, 0 };
     double vis_in_unclean = 0, q_total = 0, zero_q = 0, zero_cost = 0, zero_vis = 0, vis_cost = 0, occ_cost = 0;
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : hits, clean, allvis, allocc, mixed, cost_total, cost_clean, cost_allvis, cost_allocc, cost_mixed, beam_visits, beam_tris, beam_visits_clean, beam_tris_clean, wrong, fail_own, fail_far, fail_overflow, vis_in_unclean, q_total, zero_q, zero_cost, zero_vis, vis_cost, occ_cost, scout_work[:4], scout_tried[:4], scout_found[:4], order_work[:6], order_occ[:6], top_tests[:5], top_roots[:5], top_visits[:5], top_tris[:5], top_occ[:5], fallbacks)
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : hits, clean, allvis, allocc, mixed, cost_total, cost_clean, cost_allvis, cost_allocc, cost_mixed, beam_visits, beam_tris, beam_visits_clean, beam_tris_clean, wrong, fail_own, fail_far, fail_overflow, vis_in_unclean, q_total, zero_q, zero_cost, zero_vis, vis_cost, occ_cost, scout_work[:4], scout_tried[:4], scout_found[:4], order_work[:6], order_occ[:6], top_tests[:5], top_roots[:5], top_visits[:5], top_tris[:5], top_occ[:5], fallbacks, sah_visits[:6], sah_tris[:6], sah_occ[:6]) reduction(max : sah_maxsp)
     for (int y = 0; y < cam->height; y += step) {
         for (int x = 0; x < cam->width; x += step) {
             Ctx c { *bvh, features, 5, 0u };
@@ -294,6 +446,18 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
                         Ctx c2 { *bvh, features, 5, 0u };
                         if (!shadow_coarse(c2, nr, hit, occ2))
                             fallbacks += 1;
+                    }
+                    {
+                        Ray nr = { P, pos - P, 1.0f };
+                        nr.o = nr.o + normalize(nr.d) * 0.001f;
+                        for (int v = 0; v < 2; ++v)
+                            for (int m = 0; m < 3; ++m) {
+                                double vv = 0, tt = 0;
+                                int msp = 0;
+                                const bool occ = sah_walk(c, sah[v], nr, hit, m, &vv, &tt, &msp);
+                                sah_visits[v * 3 + m] += vv, sah_tris[v * 3 + m] += tt, sah_occ[v * 3 + m] += occ;
+                                if (msp > sah_maxsp) sah_maxsp = msp;
+                            }
                     }
                     orc_counters b4 = c.cnt;
                     const bool vis = visibility(c, pos, ray, hit) != 0.0f;
@@ -454,6 +618,8 @@ void sim_beam(const orc_bvh* bvh, const orc_camera* cam, uint32_t features, int 
     for (int m = 0; m < 6; ++m) *o++ = order_work[m], *o++ = order_occ[m];
     for (int D = 2; D <= 4; ++D) *o++ = top_tests[D], *o++ = top_roots[D], *o++ = top_visits[D], *o++ = top_tris[D], *o++ = top_occ[D];
     *o++ = fallbacks;
+    for (int k = 0; k < 6; ++k) *o++ = sah_visits[k], *o++ = sah_tris[k], *o++ = sah_occ[k];
+    *o++ = (double)sah_maxsp; *o++ = (double)sah[0].nodes.size();
     *o++ = zero_q, *o++ = zero_cost, *o++ = zero_vis, *o++ = vis_cost, *o++ = occ_cost;
 }
 }
