@@ -204,6 +204,10 @@ SRT_DI bool traverse_linear(const SceneDev& sc, f3 o, f3 d, float& T, uint32_t& 
  * both kinds of work in one trip.  Which lane advances when does not change any
  * lane's own visiting order.  FAST selects div_by for the slab divisions.  (Shadow queries, whose caller only
  * asks "accepted something and final t < 0.99", have a walk of their own further down: swalk_*.) */
+/* A walk that has ended stands on SRT_WALK_DONE, which no reference equals (as a leaf reference it would pass 2^24
+ * triangles).  Read as a signed number, `cur >= 0` is an inner node, `cur < -1` a leaf and -1 the ended walk: the wave's
+ * votes are then lane masks straight out of one compare each. */
+#define SRT_WALK_DONE 0xFFFFFFFFu
 /* One BVH query in flight on a lane. */
 struct Walk {
     f3 o, d;
@@ -231,7 +235,7 @@ SRT_DI void walk_begin(const SceneDev& sc, Walk& w, f3 o, f3 d, float T0, Stats&
     if (COUNT)
         st.box += 1;
     w.alive = val < w.C && (pass || !CULL);
-    w.cur = sc.root_ref;
+    w.cur = w.alive ? sc.root_ref : SRT_WALK_DONE;
     w.hitTri = 0xFFFFFFFFu;
     w.sp = 0;
 }
@@ -247,6 +251,7 @@ SRT_DI bool walk_pop(Walk& w, const uint2* stk)
             return true;
         }
     }
+    w.cur = SRT_WALK_DONE;
     return false;
 }
 
@@ -319,8 +324,8 @@ SRT_DI void walk_leaf(const SceneDev& sc, Walk& w, const uint2* stk, Stats& st)
 template <bool CULL, bool COUNT, bool FAST>
 SRT_DI bool walk_trip(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
 {
-    const bool atLeaf = w.alive && (w.cur & SRT_LEAF_FLAG);
-    const bool atInner = w.alive && !(w.cur & SRT_LEAF_FLAG);
+    const bool atLeaf = (int)w.cur < -1;
+    const bool atInner = (int)w.cur >= 0;
     const unsigned long long mInner = ballot64(atInner), mLeaf = ballot64(atLeaf);
     if ((mInner | mLeaf) == 0)
         return false;
@@ -841,7 +846,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary_refill(SceneDev s
     Walk w;
     w.alive = false;
     w.o = mk3(0, 0, 0), w.d = mk3(0, 0, 1);
-    w.cur = 0, w.sp = 0, w.T = SRT_FLT_MAX, w.C = SRT_FLT_MAX, w.hitTri = 0xFFFFFFFFu;
+    w.cur = SRT_WALK_DONE, w.sp = 0, w.T = SRT_FLT_MAX, w.C = SRT_FLT_MAX, w.hitTri = 0xFFFFFFFFu;
     w.rr.x = w.rr.y = w.rr.z = 0.0f;
     uint32_t item = 0;
     bool busy = false; /* the lane holds a ray: in flight (w.alive) or finished and waiting to be handed in */
@@ -903,7 +908,7 @@ __global__ __launch_bounds__(SRT_BLOCK) void k_trace_secondary_refill(SceneDev s
                         uint32_t tri = 0xFFFFFFFFu;
                         const bool h = traverse_loop<CULL, COUNT, false>(sc, o, d, T, tri, stk, st);
                         w.o = o, w.d = d, w.T = T, w.hitTri = tri, w.C = h ? T : SRT_FLT_MAX;
-                        w.alive = false;
+                        w.alive = false, w.cur = SRT_WALK_DONE;
                     }
                 }
             }
@@ -1059,10 +1064,6 @@ SRT_DI bool shadow_walk_exact(const SceneDev& sc, f3 o, f3 d, uint32_t* stk, Sta
     }
 }
 
-/* A shadow walk that has ended stands on SRT_WALK_DONE, which no reference equals (as a leaf reference it would pass
- * 2^24 triangles).  Read as a signed number, `cur >= 0` is an inner node, `cur < -1` a leaf and -1 the ended walk: the
- * wave's votes are then lane masks straight out of one compare each. */
-#define SRT_WALK_DONE 0xFFFFFFFFu
 SRT_DI void swalk_pop(Walk& w, const uint32_t* stk)
 {
     if (w.top == stk) {
