@@ -2372,7 +2372,7 @@ static size_t stack_bytes(const srt_scene* s) { return (size_t)stack_entries(s) 
 /* Entries of the shadow kernel's per-lane stacks.  The walks on binary nodes need one per level.  A wide node can leave
  * three siblings pending and wants three free entries and a spare one whenever it stacks (swalk_inner_wide), so a tree
  * of L levels - (L - 1 + 1) / 2 wide levels - can never overflow 3 * wide levels + 1 entries; shallow trees get that,
- * deeper ones at least 19 (what an 18-level tree's L + 1 comes to, and what seven blocks per compute unit leave room
+ * deeper ones at least 19 (what an 18-level tree's L + 1 comes to, and what six blocks per compute unit leave room
  * for) and the rare query that wants more is answered by the exact walk. */
 static uint32_t shadow_stack_entries(uint32_t num_levels)
 {
