@@ -364,6 +364,24 @@ def test_coarse_shadow_boxes(orc, pair, name, res):
         assert gc["inner_visits"] < ec["inner_visits"]
 
 
+@pytest.mark.parametrize("name,res", [("cornell_parallelogram", (96, 96)), ("monkey", (128, 96)), ("teapot", (96, 54))])
+def test_shadow_walk_on_compact_and_full_triangle_records(scenes, gpu, monkeypatch, name, res):
+    """The coarse shadow walk tests triangles on 48-byte records (normal + vertices; the plane offset and the second
+    operands of the inside tests recomputed).  SRT_FULL_SHADOW_TRIANGLES, read when a scene is created, keeps the walk on
+    the 96-byte records: same frame bit for bit, same work."""
+    d = scenes(name)
+    feat = SH | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_RECURSIVE | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
+    compact = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL).render(srt.make_camera(*res), feat, flags=srt.RENDER_STATS)
+    monkeypatch.setenv("SRT_FULL_SHADOW_TRIANGLES", "1")
+    gb = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL)
+    monkeypatch.delenv("SRT_FULL_SHADOW_TRIANGLES")
+    full = gb.render(srt.make_camera(*res), feat, flags=srt.RENDER_STATS)
+    assert np.array_equal(compact["rgb"].view(np.uint32), full["rgb"].view(np.uint32))
+    for key in ("path_rays", "shadow_rays", "shaded_hits", "inner_visits", "tri_tests", "box_tests"):  # (wave steps depend on scheduling)
+        assert compact["counters"][key] == full["counters"][key], key
+    assert compact["counters"]["tri_tests"] > 0
+
+
 @pytest.mark.parametrize("cap", [0, 2, 5])
 def test_coarse_shadow_stack_overflow(orc, scenes, gpu, monkeypatch, cap):
     """A wide node can leave three siblings pending, the stack holds levels + 1 entries: a query that wants more is
@@ -939,3 +957,71 @@ def test_device_tree_equals_the_oracle_tree(orc, scenes, gpu, name):
         stack.append((int(n["left"]), a))
         stack.append((int(n["right"]), b))
     assert inner == len(nodes) and leaves == ob.num_leaves and inner + leaves == len(meta)
+
+
+def test_uploaded_triangle_records_that_do_not_recompute_keep_the_full_records(orc, scenes, gpu, monkeypatch):
+    """srt_scene_upload takes the 96-byte triangle records as given.  The coarse shadow walk's 48-byte records are only
+    derived when the plane offset and the inside-test operands recomputed from normal and vertices equal the stored
+    ones.  Here every other record gets its first operand negated (under the stored records' semantics those triangles
+    can no longer be hit by any ray): the scene must keep the full records for its shadow walk, i.e. render the frame
+    it renders with SRT_FULL_SHADOW_TRIANGLES set, and not the one of the untouched table."""
+    import ctypes as C
+    hip = C.CDLL(os.path.join(os.path.dirname(srt.__file__), "csrc", "libsrt_hip.so"))
+    hip.srt_last_error.restype = C.c_char_p
+
+    class Desc(C.Structure):
+        _fields_ = [("nodes", C.c_void_p), ("n_nodes", C.c_uint32), ("root_box", C.c_float * 6), ("root_ref", C.c_uint32),
+                    ("num_levels", C.c_uint32), ("tris", C.c_void_p), ("attrs", C.c_void_p), ("n_tris", C.c_uint32),
+                    ("scene_order", C.c_void_p), ("materials", C.c_void_p), ("n_materials", C.c_uint32), ("textures", C.c_void_p),
+                    ("n_textures", C.c_uint32), ("texels", C.c_void_p), ("n_texels", C.c_uint64), ("lights", C.c_void_p),
+                    ("n_lights", C.c_uint32), ("environment", C.c_uint32)]
+
+    d = dict(scenes("monkey"))
+    d["lights"] = np.concatenate([np.asarray(d["lights"], np.float32).reshape(-1, orc.LIGHT_STRIDE),
+                                  np.asarray(orc.parallelogram_light((-0.3, 1.4, -0.3), (0.6, 0, 0), (0, 0, 0.6), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 1, 1)),
+                                             np.float32).reshape(1, -1)])
+    t = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL).download()
+    mats = np.zeros((len(d["materials"]), 12), np.float32)
+    mats[:, :8] = d["materials"]
+    mats.view(np.int32)[:, 8] = -1
+    lights = np.zeros((len(d["lights"]), 24), np.float32)
+    lights[:, 1:22] = d["lights"][:, 1:22]
+    lights.view(np.uint32)[:, 0] = d["lights"][:, 0].astype(np.uint32)
+    cam = srt.make_camera(96, 72)
+    feat = SH | srt.F_ACCEL | srt.F_HARD_SHADOW | srt.F_SOFT_SHADOW | srt.F_MISS_CULL | srt.F_COARSE_SHADOW
+
+    def frame(tris):
+        dev, scene = C.c_void_p(), C.c_void_p()
+        assert hip.srt_device_create(0, C.byref(dev)) == 0, hip.srt_last_error()
+        desc = Desc()
+        desc.nodes, desc.n_nodes = t["nodes"].ctypes.data, len(t["nodes"])
+        desc.root_box[:] = [float(x) for x in t["root_box"]]
+        desc.root_ref, desc.num_levels = t["root_ref"], t["num_levels"]
+        desc.tris, desc.attrs, desc.n_tris = tris.ctypes.data, t["attrs"].ctypes.data, len(tris)
+        desc.scene_order = t["scene_order"].ctypes.data
+        desc.materials, desc.n_materials = mats.ctypes.data, len(mats)
+        desc.lights, desc.n_lights = lights.ctypes.data, len(lights)
+        assert hip.srt_scene_upload(dev, C.byref(desc), C.byref(scene)) == 0, hip.srt_last_error()
+        p = srt.RenderParams()
+        p.camera, p.features, p.samples_x, p.samples_y, p.max_depth, p.seed = cam, feat, 1, 1, 5, 0
+        p.rect[:] = [0, 0, cam.width, cam.height]
+        rgb = np.zeros((cam.height, cam.width, 3), np.float32)
+        out = srt.Output()
+        out.rgb, out.out_width, out.out_height = rgb.ctypes.data, cam.width, cam.height
+        assert hip.srt_render(dev, scene, C.byref(p), C.byref(out), None) == 0, hip.srt_last_error()
+        hip.srt_scene_destroy(scene)
+        hip.srt_device_destroy(dev)
+        return rgb
+
+    untouched = frame(t["tris"])
+    holes = t["tris"].copy()
+    holes["c0"][1::2] *= -1
+    default = frame(holes)
+    monkeypatch.setenv("SRT_FULL_SHADOW_TRIANGLES", "1")
+    forced = frame(holes)
+    monkeypatch.delenv("SRT_FULL_SHADOW_TRIANGLES")
+    assert np.array_equal(default.view(np.uint32), forced.view(np.uint32))
+    assert not np.array_equal(default.view(np.uint32), untouched.view(np.uint32))
+    # and the untouched table is the frame of the device-built scene
+    built = srt.Bvh(srt.Scene.from_arrays(d), srt.F_ACCEL).render(cam, feat)
+    assert np.array_equal(untouched.view(np.uint32), built["rgb"].view(np.uint32))
