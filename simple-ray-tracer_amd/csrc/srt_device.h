@@ -141,17 +141,11 @@ SRT_DI bool slab_test_fast(const float lo[3], const float hi[3], f3 o, f3 d, Ray
     const float toutz = div_by((nz ? lo[2] : hi[2]) - o.z, d.z, r.z);
     const float tin = __builtin_fmaxf(tinx, __builtin_fmaxf(tiny, tinz));
     const float tout = __builtin_fminf(toutx, __builtin_fminf(touty, toutz));
-    inside = false;
-    if (tin > tout || tout < 0 || tin > T) {
-        val = T;
-        return false;
-    }
-    val = tin;
-    if (tin <= 0) {
-        val = tout;
-        inside = true;
-    }
-    return true;
+    /* slab_test's two ifs as selects (nested exec-mask regions otherwise, twice per visit) */
+    const bool pass = !(tin > tout || tout < 0 || tin > T);
+    inside = pass && tin <= 0;
+    val = pass ? (inside ? tout : tin) : T;
+    return pass;
 }
 
 /* Ray/triangle test, reference src/intersect.cpp:13-77, on a precomputed srt_tri record (six float4).

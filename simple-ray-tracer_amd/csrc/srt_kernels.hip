@@ -274,19 +274,17 @@ SRT_DI void walk_inner(const SceneDev& sc, Walk& w, uint2* stk, Stats& st)
     const bool rpass = FAST ? slab_test_fast(rlo, rhi, w.o, w.d, w.rr, w.T, rval, rin) : slab_test(rlo, rhi, w.o, w.d, w.T, rval, rin);
     const bool pushL = lval < w.C && (lpass || !CULL);
     const bool pushR = rval < w.C && (rpass || !CULL);
+    /* one conditional store, one select, one branch for the pop (a four-way if / else chain compiles to four nested
+     * exec-mask regions) */
     if (pushL && pushR) {
         /* pending left sibling; v as described at the top of the file */
         const float v = CULL ? lval : ((lpass && lin) ? lval : -1.0f);
         stk[w.sp * SRT_BLOCK] = make_uint2(left, __float_as_uint(v));
         ++w.sp;
-        w.cur = right;
-    } else if (pushR) {
-        w.cur = right;
-    } else if (pushL) {
-        w.cur = left;
-    } else {
-        w.alive = walk_pop(w, stk);
     }
+    w.cur = pushR ? right : left;
+    if (!(pushL || pushR))
+        w.alive = walk_pop(w, stk);
 }
 
 /* Visit of the leaf the lane stands on: its triangles in stored order (reference :359-368). */
