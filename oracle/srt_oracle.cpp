@@ -689,21 +689,20 @@ bool shadow_coarse(Ctx& c, const Ray& ray, const HitInfo& like, bool& occluded)
 
 /* ---------------------------------------------------------------- lights */
 
-inline uint32_t mix32(uint32_t h, uint32_t k)
+/* the arguments folded into one word, each times an odd constant of its own, then one two-multiplication finaliser */
+inline uint32_t final32(uint32_t x)
 {
-    h ^= k;
-    h *= 0x9E3779B1u;
-    h ^= h >> 15;
-    h *= 0x85EBCA77u;
-    h ^= h >> 13;
-    h *= 0xC2B2AE3Du;
-    h ^= h >> 16;
-    return h;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
 }
 inline float rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim)
 {
-    uint32_t h = mix32(mix32(mix32(mix32(mix32(seed, path), depth), light), sample), dim);
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
+    const uint32_t x = seed ^ (path * 0x9E3779B1u) ^ (depth * 0x85EBCA77u) ^ (light * 0xC2B2AE3Du) ^ (sample * 0x27D4EB2Fu) ^ (dim * 0x165667B1u);
+    return (float)(final32(x) >> 8) * (1.0f / 16777216.0f);
 }
 
 /* testVisibilityLightSample, src/light.cpp:43-74 */

@@ -313,12 +313,20 @@ SRT_DI uint32_t mix32(uint32_t h, uint32_t k)
     h ^= h >> 16;
     return h;
 }
+/* The arguments are folded into one word (each times an odd constant of its own) and that word goes through one
+ * two-multiplication finaliser: eight multiplications for the two coordinates of an area-light sample, where a chain of
+ * one full mixing round per argument took eighteen (the sampler was 2.5 % of the dragon frame). */
+SRT_DI uint32_t final32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 SRT_DI float rand01(uint32_t seed, uint32_t path, uint32_t depth, uint32_t light, uint32_t sample, uint32_t dim)
 {
-#ifdef SRT_EXPERIMENT_CHEAP_RAND
-    uint32_t hh = (seed ^ path) + depth * 977u + light * 131u + sample * 7919u + dim * 104729u; /* timing experiment only */
-    return (float)(hh & 0xFFFFFFu) * (1.0f / 16777216.0f);
-#endif
-    uint32_t h = mix32(mix32(mix32(mix32(mix32(seed, path), depth), light), sample), dim);
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
+    const uint32_t x = seed ^ (path * 0x9E3779B1u) ^ (depth * 0x85EBCA77u) ^ (light * 0xC2B2AE3Du) ^ (sample * 0x27D4EB2Fu) ^ (dim * 0x165667B1u);
+    return (float)(final32(x) >> 8) * (1.0f / 16777216.0f);
 }
