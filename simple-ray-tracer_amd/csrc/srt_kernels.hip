@@ -1475,13 +1475,25 @@ __global__ __launch_bounds__(SRT_SHADOW_BLOCK, SRT_SHADOW_WAVES) void k_trace_sh
                 const uint32_t h = hb + over;
                 uint32_t k = within - over * shadows_per_hit;
                 const float4 hp = hq.ip[h]; /* hit point and sampler key, left by the trace kernel */
+                /* which light the sample belongs to: the lights in LDS first, in a loop of their own (one loop over both
+                 * kinds reads the type through a flat load and waits for every load in flight, the hit point's included) */
                 uint32_t li = 0;
-                for (; li < sc.n_lights; ++li) {
-                    const uint32_t type = li < nLdsLights ? lds_lights[li].type : sc.lights[li].type;
-                    const uint32_t c = shadow_samples(type, rp.features);
-                    if (k < c)
+                bool found = false;
+                for (; li < nLdsLights; ++li) {
+                    const uint32_t c = shadow_samples(lds_lights[li].type, rp.features);
+                    if (k < c) {
+                        found = true;
                         break;
+                    }
                     k -= c;
+                }
+                if (!found) {
+                    for (; li < sc.n_lights; ++li) {
+                        const uint32_t c = shadow_samples(sc.lights[li].type, rp.features);
+                        if (k < c)
+                            break;
+                        k -= c;
+                    }
                 }
                 srt_light L;
                 if (li < nLdsLights)
