@@ -491,6 +491,8 @@ SRT_DI void light_sample(const srt_light* L, uint32_t seed, uint32_t path, uint3
     }
 }
 
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+
 /* The shade kernel's half: lights and samples in the reference's order; vis holds this hit's visibility bits
  * (one byte each) starting at index bit0. */
 SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t seed, uint32_t path, uint32_t depth, f3 o, f3 d, float T,
@@ -534,8 +536,13 @@ SRT_DI f3 light_contribution(const SceneDev& sc, uint32_t features, uint32_t see
             }
         } else {
             /* segment: 100 samples, each weighted 1/100; parallelogram: 10 x 10 samples, each weighted 1/100 */
+            /* the sample's visibility bytes four at a time (the buffer is padded beyond its last byte; a hit's bytes
+             * start anywhere, the hardware reads unaligned words) */
+            uint32_t word = 0;
             for (uint32_t k = 0; k < n; ++k) {
-                const uint32_t v = vis[bit + k];
+                if ((k & 3u) == 0u)
+                    word = *(const u32_unaligned*)(vis + bit + k);
+                const uint32_t v = (word >> ((k & 3u) * 8u)) & 0xFFu;
                 if (v != 0u || !tame) {
                     f3 pos, col;
                     light_sample(L, seed, path, depth, li, k, pos, col);
