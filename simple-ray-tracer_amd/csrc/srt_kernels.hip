@@ -1748,6 +1748,32 @@ SRT_DI f3 sample_value(const RenderDev& rp, const float* acc, const float* chain
 /* Pixel value from its samples (reference src/render.cpp:213-217) stored at Screen::setPixel's position. */
 __global__ __launch_bounds__(SRT_BLOCK) void k_resolve(RenderDev rp, const float* acc, const float* chain, const unsigned char* nlev)
 {
+    if (!rp.custom_rays && !rp.lens_mode && !chain && (rp.features & SRT_F_MULTISAMPLE) && (rp.S & 3) == 0) {
+        /* The common large frame (n x m samples, a multiple of four, no parked reflection levels): threads take the
+         * pixels in the order their samples are stored, so a wave reads one contiguous stretch of the accumulators,
+         * four samples (three 16-byte loads) at a time; same additions in the same order as below. */
+        const uint32_t n_slots = blocks_x(rp) * (((uint32_t)rp.th + 7u) >> 3) * 64u;
+        for (uint32_t q = blockIdx.x * SRT_BLOCK + threadIdx.x; q < n_slots; q += gridDim.x * SRT_BLOCK) {
+            int px, py, sub;
+            const uint32_t first = q * (uint32_t)rp.S;
+            if (!sample_decode(rp, first, px, py, sub))
+                continue; /* padding of a block at the rectangle's right or top edge */
+            const float4* a4 = (const float4*)(acc + 3ull * first);
+            f3 c = mk3(0, 0, 0);
+            for (int s4 = 0; s4 < rp.S; s4 += 4) {
+                const float4 u = a4[0], v = a4[1], w = a4[2];
+                a4 += 3;
+                c = c + mk3(u.x, u.y, u.z);
+                c = c + mk3(u.w, v.x, v.y);
+                c = c + mk3(v.z, v.w, w.x);
+                c = c + mk3(w.y, w.z, w.w);
+            }
+            c = c / (float)rp.S;
+            float* o = rp.out_rgb + 3 * out_index(rp, px, py);
+            o[0] = c.x, o[1] = c.y, o[2] = c.z;
+        }
+        return;
+    }
     const uint32_t n_px = (uint32_t)rp.tw * (uint32_t)rp.th;
     for (uint32_t p = blockIdx.x * SRT_BLOCK + threadIdx.x; p < n_px; p += gridDim.x * SRT_BLOCK) {
         const int py = rp.y0 + (int)(p / (uint32_t)rp.tw), px = rp.x0 + (int)(p % (uint32_t)rp.tw);
