@@ -147,8 +147,8 @@ SRT_DI void flush_counters(DevCounters* c, uint32_t path, uint32_t shadow, uint3
 /* Records of the traversal arrays by 32-bit byte offset from the array's base: the base is wave-uniform (a kernel
  * argument), so the load takes it from scalar registers and the lane supplies one shifted index, where 64-bit pointer
  * arithmetic costs the lane a 64-bit shift and a 64-bit add per visit (dragon shadow launch 98.4 -> 96.7 ms).  The
- * arrays stay below 4 GiB: at most 2^24 triangles of 96 bytes, fewer than 2^25 nodes of 64 bytes (srt_scene_upload
- * checks).  The empty asm keeps the offset a 32-bit value of its own where a loop would otherwise turn it into a
+ * arrays stay below 4 GiB: at most 2^24 triangles of 96 bytes, fewer than 2^26 nodes of 64 bytes (srt_scene_upload
+ * checks both).  The empty asm keeps the offset a 32-bit value of its own where a loop would otherwise turn it into a
  * 64-bit induction pointer. */
 SRT_DI const float4* node_record(const SceneDev& sc, uint32_t i)
 {
@@ -1337,10 +1337,9 @@ SRT_DI int swalk_leaf(const SceneDev& sc, Walk& w, const uint32_t* stk, Stats& s
     const uint32_t cnt = (w.cur >> 24) & 0x7Fu;
     float T = 1.0f;
     bool hit = false;
-    /* One triangle after the other, on the full record (plane, vertices and the stored second operands of the inside
-     * test).  Most visits are of a single triangle: the wide records list the triangles of small leaves one by one.
-     * (Testing a leaf's triangles in pairs and recomputing the stored operands from the vertices paid while the kernel
-     * was short of loads per lane; with the wide records it is short of vector instructions: 107.9 -> 106.1 ms.) */
+    /* One triangle after the other; most visits are of a single triangle (the wide records list the triangles of small
+     * leaves one by one).  COMPACT: on the scene's 48-byte shadow records (normal and vertices; three loads per test, the
+     * plane offset and the second operands of the inside test recomputed), else on the full 96-byte traversal records. */
     if (COMPACT) {
         for (uint32_t k = 0; k < cnt; ++k) {
             if (COUNT)
