@@ -252,7 +252,10 @@ int srt_device_kernel_times(srt_device* dev, float ms[SRT_KERNEL_FAMILIES], int3
 
 /* What BvhInterface's constructor leaves behind (reference src/bvh_interface.h:16, src/bounding_volume_hierarchy.cpp:
  * 14-35: the node table over the Scene's meshes), flattened by the caller; copies every array of the description
- * to device memory, the host arrays stay with the caller. */
+ * to device memory, the host arrays stay with the caller.  Limits: at most 2^24 triangles, fewer than 2^26 node records,
+ * at most 30 levels (anything else is refused).  From the tables it also derives, on the device, what the shadow
+ * queries walk: four-wide records of 16-bit boxes and 48-byte triangle records (normal + vertices), about 64 bytes more
+ * per triangle of a two-triangle-leaf tree. */
 int srt_scene_upload(srt_device* dev, const srt_scene_desc* desc, srt_scene** out);
 void srt_scene_destroy(srt_scene* scene);
 
